@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Benchmark of the LightGCN propagation hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One *step* = one ``get_embedding``: LAYERS sparse hops over the whole graph with the layer sum
+fused (the work src/lightgcn.py:91-99 does per mini-batch and per serving request).
+Workload at every N: BASELINE.json configs[1] -- synthetic cosmetics-scale graph, 1,639,358 users
+x 54,571 items, 10,157,408 pairs = 20,314,816 directed edges, 3 layers, emb_dim 64, fp32.
+N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME graph, users partitioned by
+nnz-balanced ranges, items replicated, one RCCL all-reduce of the [n_items, D] block per hop
+(strong scaling).
+
+metric  = edges propagated per second per LGConv layer = nnz * LAYERS / t_step, whole job.
+roofline = algorithmic bytes of one hop (B_min, SURVEY.md 8d: nnz*8 + (N+1)*4 + 2*N*D*4) divided
+           by the mean duration of one hop's launches, measured with events on the launch stream
+           inside the timed region, against 8 TB/s HBM3E.
+cpu_baseline = the reference-semantics CPU path (oracle/, a port of the reference's PyG route:
+           unsorted COO, per-layer gcn_norm, gather -> scale -> index_add_) timed on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+LAYERS, DIM, SEED = 3, 64, 0
+HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--layers", type=int, default=LAYERS)
+    ap.add_argument("--dim", type=int, default=DIM)
+    ap.add_argument("--config", choices=["cosmetics", "small"], default="cosmetics")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(graph, layers, dim):
+    """Reference-semantics CPU path on a bounded sample: ONE full K-layer propagate of the same graph
+    after a one-layer warm-up (about 4 layer-times of CPU work)."""
+    from oracle import lightgcn_oracle as oracle
+    from gnn_ecommerce_amd import synth
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    torch.set_num_threads(cores)
+    ei, ew = graph.coo()
+    w0 = synth.xavier_table(graph.num_nodes, dim, SEED)
+    with torch.no_grad():
+        oracle.lgconv(w0, ei, ew)                     # warm-up (allocator, thread pool)
+        t0 = time.perf_counter()
+        oracle.get_embedding(w0, oracle.default_alpha(layers), ei, ew, layers)
+        dt = time.perf_counter() - t0
+    return {"value": graph.nnz * layers / dt, "unit": "edges/s", "cores": cores, "kind": "port",
+            "sample": f"1 full {layers}-layer get_embedding of the same graph ({graph.nnz} edges, D={dim}), "
+                      f"torch {torch.__version__} CPU fp32, {dt:.2f} s, after a 1-layer warm-up"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        args.gpus = world
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import gnn_ecommerce_amd as lg
+    from gnn_ecommerce_amd import propagate, synth
+
+    cfg = synth.CONFIG_COSMETICS if args.config == "cosmetics" else synth.CONFIG_SMALL
+    t0 = time.perf_counter()
+    graph = synth.make_bipartite(**cfg, seed=SEED)
+    t_gen = time.perf_counter() - t0
+    n, nnz = graph.num_nodes, graph.nnz
+    alphas = tuple([1.0 / (args.layers + 1)] * (args.layers + 1))
+    x0 = synth.xavier_table(n, args.dim, SEED, dev)
+    ei, ew = graph.coo(dev)
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if world == 1:
+        pg = lg.PropGraph(ei, ew, n)
+        step = lambda: propagate.propagate_sum(x0, pg, alphas)
+        parallelism = "single"
+    else:
+        from gnn_ecommerce_amd.partition import PartitionedPropagator
+        pp = PartitionedPropagator(ei, ew, graph.n_users, graph.n_items, rank, world)
+        step = lambda: pp.propagate_sum(x0, alphas)
+        parallelism = f"user-range x{world}, items replicated, all-reduce [n_items,D]/hop"
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t0
+    del ei, ew
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    propagate.HOP_EVENT_LOG = []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    hop_events, propagate.HOP_EVENT_LOG = propagate.HOP_EVENT_LOG, None
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+
+    hop_ms = [s.elapsed_time(e) for s, e in hop_events]
+    hop_mean_s = sum(hop_ms) / max(len(hop_ms), 1) * 1e-3
+    bmin = synth.algorithmic_bytes_per_layer(n, nnz, args.dim)
+    achieved = bmin / hop_mean_s if hop_mean_s > 0 else 0.0
+    if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if world == 1 and os.path.isfile(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get(f"{args.config}_d{args.dim}")
+        line = {
+            "metric": "edges propagated/sec per LGConv layer",
+            "value": nnz * args.layers * args.steps / elapsed,
+            "unit": "edges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"configs[1]: {graph.n_users} users x {graph.n_items} items, "
+                                   f"{nnz} directed edges, {args.layers} LGConv layers, emb_dim {args.dim}, "
+                                   "get_embedding (K hops + fused layer sum)",
+                       "parallelism": parallelism, "seed": SEED,
+                       "graph_build_s": round(t_build, 3), "synth_gen_s": round(t_gen, 1)},
+            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK, "traffic": traffic,
+                         "kernel": "one hop = lgc_spmm (k_spmm_rows + k_spmm_chunks + k_spmm_combine)",
+                         "algorithmic_bytes_per_launch": bmin, "launch_ms": hop_mean_s * 1e3,
+                         "launches_timed": len(hop_ms)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(graph, args.layers, args.dim)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

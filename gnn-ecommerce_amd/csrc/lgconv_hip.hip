@@ -1,0 +1,626 @@
+// lgconv_hip.hip -- LightGCN propagation for MI355X (gfx950, CDNA4).  C ABI: include/lgconv_hip.h
+//
+// Memory-bound sparse aggregation (<= 2.5 FLOP/B): no MFMA, no LDS tiling of operands.
+// What matters here is (1) every embedding row moving as full-width, coalesced vector
+// loads/stores -- one *lane group* of LPR = ceil(D/4) lanes owns a row and each lane a
+// float4 of it, so a 64-wide wavefront carries 64/LPR rows per instruction (4 at D=64);
+// (2) many independent row gathers in flight per wave (4-way unrolled entry loop, 8 waves
+// per SIMD at <= 64 VGPRs); (3) no float atomics on the forward path: long rows are cut into
+// chunks whose partial sums are combined in a fixed order.
+//
+// Kernels
+//   k_build_*        one-time COO -> CSR (+ reference-order fp32 degree, normalised values)
+//   k_spmm_rows      rows with <= short_max entries, one lane group per row, entry order
+//   k_spmm_chunks    one wavefront per chunk of a long row, lane groups stride the entries,
+//                    cross-group reduce through ds_bpermute shuffles
+//   k_spmm_combine   fixed-order sum of a long row's partial slots + epilogue
+//   k_axpby, k_pair_dot, k_pair_dot_bwd
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+#include <cstdint>
+
+#include "lgconv_hip.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;  // 4 wavefronts, one per SIMD of a CU
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+// Row bases are only 8-byte aligned when D % 4 != 0 (D = 90 -> 360-byte rows): tell the
+// compiler, it still emits global_load_dwordx4 (gfx950 allows dword-aligned wide accesses).
+typedef f4 f4u __attribute__((aligned(4)));
+
+inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ----------------------------------------------------------------------------------------
+// Graph build
+// ----------------------------------------------------------------------------------------
+__global__ void k_build_keys(const int64_t *__restrict__ edge_index, int64_t n_edges, int64_t n_nodes,
+                             int by_source, int32_t *__restrict__ keys, int32_t *__restrict__ ids,
+                             int32_t *__restrict__ status) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_edges) return;
+    int64_t src = edge_index[e], dst = edge_index[n_edges + e];
+    bool ok = src >= 0 && src < n_nodes && dst >= 0 && dst < n_nodes;
+    if (!ok) atomicOr(status, LGC_ST_INDEX_OOB);
+    // an invalid edge is parked on row 0 and later given value 0 / column 0
+    keys[e] = ok ? (int32_t)(by_source ? src : dst) : 0;
+    ids[e] = (int32_t)e;
+}
+
+__global__ void k_build_rowptr(const int32_t *__restrict__ sorted_keys, int32_t n_edges, int32_t n_nodes,
+                               int32_t *__restrict__ rowptr) {
+    int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_nodes) return;
+    int32_t lo = 0, hi = n_edges;  // first position whose key >= r
+    while (lo < hi) {
+        int32_t mid = lo + ((hi - lo) >> 1);
+        if (sorted_keys[mid] < r) lo = mid + 1; else hi = mid;
+    }
+    rowptr[r] = lo;
+}
+
+__global__ void k_build_sorted_weight(const int32_t *__restrict__ perm, const float *__restrict__ w,
+                                      int32_t n_edges, float *__restrict__ w_sorted) {
+    int32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_edges) w_sorted[k] = w ? w[perm[k]] : 1.0f;
+}
+
+constexpr int kDegSerialMax = 512;
+
+// deg[r] = ((0 + w_0) + w_1) + ...  in edge order: bitwise what a sequential CPU scatter_add gives.
+__global__ void k_build_degree_serial(const int32_t *__restrict__ rowptr, const float *__restrict__ w_sorted,
+                                      int32_t n_nodes, float *__restrict__ deg) {
+    int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_nodes) return;
+    int32_t s = rowptr[r], e = rowptr[r + 1];
+    if (e - s > kDegSerialMax) return;
+    float acc = 0.0f;
+    for (int32_t k = s; k < e; ++k) acc = __fadd_rn(acc, w_sorted[k]);
+    deg[r] = acc;
+}
+
+// Hub rows: a wavefront streams the row 64 values at a time (coalesced) and lane order IS edge
+// order, so the serial chain runs over v_readlane without touching memory again.
+__global__ void k_build_degree_wave(const int32_t *__restrict__ rowptr, const float *__restrict__ w_sorted,
+                                    int32_t n_nodes, float *__restrict__ deg) {
+    int32_t r = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    if (r >= n_nodes) return;
+    int32_t s = rowptr[r], e = rowptr[r + 1];
+    if (e - s <= kDegSerialMax) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    float acc = 0.0f;
+    for (int32_t base = s; base < e; base += kWave) {
+        int32_t k = base + lane;
+        float v = k < e ? w_sorted[k] : 0.0f;
+        int n = min(kWave, e - base);
+        if (n == kWave) {
+#pragma unroll
+            for (int i = 0; i < kWave; ++i) acc = __fadd_rn(acc, __shfl(v, i));
+        } else {
+            for (int i = 0; i < n; ++i) acc = __fadd_rn(acc, __shfl(v, i));
+        }
+    }
+    if (lane == 0) deg[r] = acc;
+}
+
+__global__ void k_build_dis(const float *__restrict__ deg, int32_t n_nodes, float *__restrict__ dis) {
+    int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_nodes) return;
+    // deg^-1/2 as 1/sqrt with both steps correctly rounded; +inf (deg == 0) -> 0, NaN (deg < 0) stays.
+    float d = __fdiv_rn(1.0f, __fsqrt_rn(deg[r]));
+    dis[r] = (d == INFINITY) ? 0.0f : d;
+}
+
+__global__ void k_build_entries(const int64_t *__restrict__ edge_index, const float *__restrict__ w,
+                                const int32_t *__restrict__ perm, const float *__restrict__ dis,
+                                int64_t n_edges, int64_t n_nodes, int by_source, int normalize,
+                                lgc_entry *__restrict__ entries, float *__restrict__ edge_val) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_edges) return;
+    int32_t e = perm[k];
+    int64_t src = edge_index[e], dst = edge_index[n_edges + e];
+    bool ok = src >= 0 && src < n_nodes && dst >= 0 && dst < n_nodes;
+    float wv = w ? w[e] : 1.0f;
+    float v = 0.0f;
+    int32_t c = 0;
+    if (ok) {
+        // left to right, each product rounded: dis[j] * w * dis[i]
+        v = normalize ? __fmul_rn(__fmul_rn(dis[src], wv), dis[dst]) : wv;
+        c = (int32_t)(by_source ? dst : src);
+    }
+    entries[k].col = c;
+    entries[k].val = v;
+    if (edge_val) edge_val[e] = v;
+}
+
+struct BuildWs {
+    int32_t *keys_in, *keys_out, *ids_in, *ids_out;
+    float *w_sorted;
+    void *cub;
+    size_t cub_bytes;
+    size_t total;
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int end_bit_for(int64_t n_nodes) {
+    int bits = 1;
+    while (bits < 31 && (int64_t(1) << bits) < n_nodes) ++bits;
+    return bits;
+}
+
+BuildWs carve_build_ws(void *base, int64_t n_nodes, int64_t n_edges) {
+    BuildWs ws{};
+    size_t cub_bytes = 0;
+    int32_t *nul = nullptr;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, nul, nul, nul, nul, (int)n_edges, 0,
+                                             end_bit_for(n_nodes), (hipStream_t)0);
+    size_t arr = align_up((size_t)n_edges * 4, 256);
+    char *p = reinterpret_cast<char *>(base);
+    ws.keys_in = reinterpret_cast<int32_t *>(p);
+    ws.keys_out = reinterpret_cast<int32_t *>(p + arr);
+    ws.ids_in = reinterpret_cast<int32_t *>(p + 2 * arr);
+    ws.ids_out = reinterpret_cast<int32_t *>(p + 3 * arr);
+    ws.w_sorted = reinterpret_cast<float *>(p);  // reuses keys_in after the sort
+    ws.cub = p + 4 * arr;
+    ws.cub_bytes = align_up(cub_bytes, 256);
+    ws.total = 4 * arr + ws.cub_bytes + 256;
+    return ws;
+}
+
+// ----------------------------------------------------------------------------------------
+// SpMM
+// ----------------------------------------------------------------------------------------
+struct SpmmArgs {
+    const int32_t *rowptr;
+    const lgc_entry *entries;
+    const float *x;
+    float *y;
+    const float *r;
+    int64_t x_stride, y_stride, r_stride;
+    float a, b;
+    int32_t dim, lpr;  // lanes per row = ceil(dim / VEC)
+    int32_t row_begin, row_end, short_max;
+};
+
+template <int VEC>
+struct Acc {
+    float v[VEC];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[i] = 0.0f;
+    }
+};
+
+// Load VEC floats of a row; the last lane of a D=90-style row holds fewer valid elements.
+template <int VEC, bool TAIL>
+__device__ __forceinline__ Acc<VEC> load_row(const float *p, int nvalid) {
+    Acc<VEC> o;
+    if constexpr (VEC == 4) {
+        if (!TAIL || nvalid == 4) {
+            f4 t = *reinterpret_cast<const f4u *>(p);
+            o.v[0] = t.x; o.v[1] = t.y; o.v[2] = t.z; o.v[3] = t.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o.v[i] = i < nvalid ? p[i] : 0.0f;
+        }
+    } else {
+        o.v[0] = p[0];
+    }
+    return o;
+}
+
+template <int VEC, bool TAIL>
+__device__ __forceinline__ void store_row(float *p, const Acc<VEC> &o, int nvalid) {
+    if constexpr (VEC == 4) {
+        if (!TAIL || nvalid == 4) {
+            f4 t = {o.v[0], o.v[1], o.v[2], o.v[3]};
+            *reinterpret_cast<f4u *>(p) = t;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < nvalid) p[i] = o.v[i];
+        }
+    } else {
+        p[0] = o.v[0];
+    }
+}
+
+// acc = acc + val * x, product rounded before the add: the arithmetic of the reference's
+// "scale the gathered rows, then index_add_" (no FMA contraction).
+template <int VEC>
+__device__ __forceinline__ void mul_add(Acc<VEC> &acc, float val, const Acc<VEC> &x) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc.v[i] = __fadd_rn(acc.v[i], __fmul_rn(val, x.v[i]));
+}
+
+template <int VEC, bool TAIL>
+__device__ __forceinline__ void epilogue_store(const SpmmArgs &p, int64_t row, int c0, int nvalid, Acc<VEC> acc) {
+    if (p.a != 1.0f) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc.v[i] = __fmul_rn(p.a, acc.v[i]);
+    }
+    if (p.r != nullptr) {
+        Acc<VEC> rv = load_row<VEC, TAIL>(p.r + row * p.r_stride + c0, nvalid);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc.v[i] = __fadd_rn(acc.v[i], __fmul_rn(p.b, rv.v[i]));
+    }
+    store_row<VEC, TAIL>(p.y + row * p.y_stride + c0, acc, nvalid);
+}
+
+// Short rows: one lane group per row, entries in order, 4 gathers in flight per group.
+template <int VEC, bool TAIL>
+__global__ __launch_bounds__(kBlock) void k_spmm_rows(SpmmArgs p) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int rows_per_wave = kWave / p.lpr;
+    const int g = lane / p.lpr;
+    const int l = lane - g * p.lpr;
+    const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x / kWave);
+    const int64_t row = (int64_t)p.row_begin + wave * rows_per_wave + g;
+    const int c0 = l * VEC;
+    const int nvalid = min(VEC, p.dim - c0);
+    if (g >= rows_per_wave || row >= p.row_end || nvalid <= 0) return;
+
+    const int32_t s = p.rowptr[row], e = p.rowptr[row + 1];
+    if (e - s > p.short_max) return;  // belongs to k_spmm_chunks
+
+    const float *xb = p.x + c0;
+    const lgc_entry *__restrict__ ent = p.entries;
+    Acc<VEC> acc;
+    acc.zero();
+    int32_t k = s;
+    for (; k + 4 <= e; k += 4) {
+        lgc_entry e0 = ent[k], e1 = ent[k + 1], e2 = ent[k + 2], e3 = ent[k + 3];
+        Acc<VEC> x0 = load_row<VEC, TAIL>(xb + (int64_t)e0.col * p.x_stride, nvalid);
+        Acc<VEC> x1 = load_row<VEC, TAIL>(xb + (int64_t)e1.col * p.x_stride, nvalid);
+        Acc<VEC> x2 = load_row<VEC, TAIL>(xb + (int64_t)e2.col * p.x_stride, nvalid);
+        Acc<VEC> x3 = load_row<VEC, TAIL>(xb + (int64_t)e3.col * p.x_stride, nvalid);
+        mul_add<VEC>(acc, e0.val, x0);
+        mul_add<VEC>(acc, e1.val, x1);
+        mul_add<VEC>(acc, e2.val, x2);
+        mul_add<VEC>(acc, e3.val, x3);
+    }
+    for (; k < e; ++k) {
+        lgc_entry e0 = ent[k];
+        Acc<VEC> x0 = load_row<VEC, TAIL>(xb + (int64_t)e0.col * p.x_stride, nvalid);
+        mul_add<VEC>(acc, e0.val, x0);
+    }
+    epilogue_store<VEC, TAIL>(p, row, c0, nvalid, acc);
+}
+
+// Long rows: one wavefront per chunk.  Lane group g takes entries begin+g, begin+g+G, ...;
+// the G group sums are then added in group order by lane group 0.
+template <int VEC, bool TAIL>
+__global__ __launch_bounds__(kBlock) void k_spmm_chunks(SpmmArgs p, const lgc_chunk *__restrict__ chunks,
+                                                       int32_t n_chunks, float *__restrict__ partials) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x / kWave);
+    if (wave >= n_chunks) return;  // wave-uniform
+    const lgc_chunk ch = chunks[wave];
+    const int groups = kWave / p.lpr;
+    const int g = lane / p.lpr;
+    const int l = lane - g * p.lpr;
+    const int c0 = l * VEC;
+    const int nvalid = min(VEC, p.dim - c0);
+    const bool active = g < groups && nvalid > 0;
+
+    Acc<VEC> acc;
+    acc.zero();
+    if (active) {
+        const float *xb = p.x + c0;
+        const lgc_entry *__restrict__ ent = p.entries;
+        int32_t k = ch.begin + g;
+        for (; k + 3 * groups < ch.end; k += 4 * groups) {
+            lgc_entry e0 = ent[k], e1 = ent[k + groups], e2 = ent[k + 2 * groups], e3 = ent[k + 3 * groups];
+            Acc<VEC> x0 = load_row<VEC, TAIL>(xb + (int64_t)e0.col * p.x_stride, nvalid);
+            Acc<VEC> x1 = load_row<VEC, TAIL>(xb + (int64_t)e1.col * p.x_stride, nvalid);
+            Acc<VEC> x2 = load_row<VEC, TAIL>(xb + (int64_t)e2.col * p.x_stride, nvalid);
+            Acc<VEC> x3 = load_row<VEC, TAIL>(xb + (int64_t)e3.col * p.x_stride, nvalid);
+            mul_add<VEC>(acc, e0.val, x0);
+            mul_add<VEC>(acc, e1.val, x1);
+            mul_add<VEC>(acc, e2.val, x2);
+            mul_add<VEC>(acc, e3.val, x3);
+        }
+        for (; k < ch.end; k += groups) {
+            lgc_entry e0 = ent[k];
+            Acc<VEC> x0 = load_row<VEC, TAIL>(xb + (int64_t)e0.col * p.x_stride, nvalid);
+            mul_add<VEC>(acc, e0.val, x0);
+        }
+    }
+    // every lane executes the shuffles; only group 0 keeps the result
+    for (int j = 1; j < groups; ++j) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float other = __shfl_down(acc.v[i], j * p.lpr);
+            if (g == 0) acc.v[i] = __fadd_rn(acc.v[i], other);
+        }
+    }
+    if (!active || g != 0) return;
+    if (ch.slot >= 0) {
+        store_row<VEC, TAIL>(partials + (int64_t)ch.slot * p.dim + c0, acc, nvalid);
+    } else {
+        epilogue_store<VEC, TAIL>(p, ch.row, c0, nvalid, acc);
+    }
+}
+
+template <int VEC, bool TAIL>
+__global__ __launch_bounds__(kBlock) void k_spmm_combine(SpmmArgs p, const lgc_multi_row *__restrict__ multi,
+                                                        int32_t n_multi, const float *__restrict__ partials) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int rows_per_wave = kWave / p.lpr;
+    const int g = lane / p.lpr;
+    const int l = lane - g * p.lpr;
+    const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x / kWave);
+    const int64_t m = wave * rows_per_wave + g;
+    const int c0 = l * VEC;
+    const int nvalid = min(VEC, p.dim - c0);
+    if (g >= rows_per_wave || m >= n_multi || nvalid <= 0) return;
+    const lgc_multi_row mr = multi[m];
+    Acc<VEC> acc;
+    acc.zero();
+    for (int32_t s = mr.slot_begin; s < mr.slot_end; ++s) {
+        Acc<VEC> t = load_row<VEC, TAIL>(partials + (int64_t)s * p.dim + c0, nvalid);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc.v[i] = __fadd_rn(acc.v[i], t.v[i]);
+    }
+    epilogue_store<VEC, TAIL>(p, mr.row, c0, nvalid, acc);
+}
+
+__global__ void k_axpby(float *__restrict__ y, int64_t y_stride, const float *__restrict__ r, int64_t r_stride,
+                        float a, float b, int64_t n_rows, int32_t dim) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = n_rows * dim;
+    for (; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t row = i / dim;
+        int32_t c = (int32_t)(i - row * dim);
+        float v = __fmul_rn(a, y[row * y_stride + c]);
+        if (r) v = __fadd_rn(v, __fmul_rn(b, r[row * r_stride + c]));
+        y[row * y_stride + c] = v;
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// Pair scoring
+// ----------------------------------------------------------------------------------------
+// One wavefront per pair; lanes stride the feature axis, butterfly reduce over 64 lanes.
+__global__ __launch_bounds__(kBlock) void k_pair_dot(const float *__restrict__ emb, int64_t stride, int32_t dim,
+                                                    int64_t n_nodes, const int64_t *__restrict__ idx0,
+                                                    const int64_t *__restrict__ idx1, int64_t n_pairs,
+                                                    float *__restrict__ scores, int32_t *__restrict__ status) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t m = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x / kWave);
+    if (m >= n_pairs) return;
+    const int64_t a = idx0[m], b = idx1[m];
+    if (a < 0 || a >= n_nodes || b < 0 || b >= n_nodes) {  // wave-uniform
+        if (lane == 0) {
+            atomicOr(status, LGC_ST_INDEX_OOB);
+            scores[m] = NAN;
+        }
+        return;
+    }
+    const float *pa = emb + a * stride, *pb = emb + b * stride;
+    float s = 0.0f;
+    for (int c = lane; c < dim; c += kWave) s += pa[c] * pb[c];
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) scores[m] = s;
+}
+
+__global__ __launch_bounds__(kBlock) void k_pair_dot_bwd(const float *__restrict__ gs, const float *__restrict__ emb,
+                                                        int64_t stride, int32_t dim, int64_t n_nodes,
+                                                        const int64_t *__restrict__ idx0,
+                                                        const int64_t *__restrict__ idx1, int64_t n_pairs,
+                                                        float *__restrict__ grad, int32_t *__restrict__ status) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t m = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x / kWave);
+    if (m >= n_pairs) return;
+    const int64_t a = idx0[m], b = idx1[m];
+    if (a < 0 || a >= n_nodes || b < 0 || b >= n_nodes) {
+        if (lane == 0) atomicOr(status, LGC_ST_INDEX_OOB);
+        return;
+    }
+    const float g = gs[m];
+    const float *pa = emb + a * stride, *pb = emb + b * stride;
+    float *ga = grad + a * stride, *gb = grad + b * stride;
+    for (int c = lane; c < dim; c += kWave) {
+        float va = pa[c], vb = pb[c];
+        atomicAdd(ga + c, g * vb);  // global_atomic_add_f32, 256 contiguous bytes per wave-instruction
+        atomicAdd(gb + c, g * va);
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// dispatch helpers
+// ----------------------------------------------------------------------------------------
+struct DimCfg {
+    int vec;    // 4 or 1
+    bool tail;  // last lane of a row holds fewer than vec elements
+    int lpr;
+};
+
+bool dim_cfg(int32_t dim, DimCfg *cfg) {
+    if (dim < 1 || dim > 256) return false;
+    if (dim % 2 == 0) {
+        cfg->vec = 4;
+        cfg->tail = dim % 4 != 0;
+        cfg->lpr = (dim + 3) / 4;
+    } else {
+        if (dim > 64) return false;
+        cfg->vec = 1;
+        cfg->tail = false;
+        cfg->lpr = dim;
+    }
+    return cfg->lpr <= kWave;
+}
+
+template <typename F>
+int dispatch_dim(const DimCfg &cfg, F &&f) {
+    if (cfg.vec == 4) {
+        if (cfg.tail) return f(std::integral_constant<int, 4>{}, std::true_type{});
+        return f(std::integral_constant<int, 4>{}, std::false_type{});
+    }
+    return f(std::integral_constant<int, 1>{}, std::false_type{});
+}
+
+bool aligned_to(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+}  // namespace
+
+// ========================================================================================
+// C ABI
+// ========================================================================================
+extern "C" {
+
+int lgc_abi_version(void) { return LGC_ABI_VERSION; }
+
+const char *lgc_error_string(int code) {
+    switch (code) {
+        case 0: return "ok";
+        case LGC_E_INVAL: return "invalid argument";
+        case LGC_E_DIM: return "unsupported embedding width";
+        case LGC_E_WORKSPACE: return "workspace too small";
+        case LGC_E_RANGE: return "node or edge count does not fit int32";
+        case LGC_E_ALIGN: return "pointer or stride alignment violated";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+    }
+}
+
+int lgc_dim_ok(int32_t dim) {
+    DimCfg cfg;
+    return dim_cfg(dim, &cfg) ? 1 : 0;
+}
+
+size_t lgc_build_workspace_bytes(int64_t n_nodes, int64_t n_edges) {
+    if (n_nodes < 0 || n_edges < 0 || n_nodes >= INT32_MAX || n_edges >= INT32_MAX) return 0;
+    return carve_build_ws(nullptr, n_nodes, n_edges > 0 ? n_edges : 1).total;
+}
+
+int lgc_build_csr(const int64_t *edge_index, const float *edge_weight, int64_t n_nodes, int64_t n_edges,
+                  int32_t by_source, int32_t normalize, const float *dis_in, int32_t *rowptr,
+                  lgc_entry *entries, float *edge_val, float *deg_out, float *dis_out, void *workspace,
+                  size_t workspace_bytes, int32_t *status, void *stream_) {
+    if (n_nodes < 0 || n_edges < 0) return LGC_E_INVAL;
+    if (n_nodes >= INT32_MAX || n_edges >= INT32_MAX) return LGC_E_RANGE;
+    if (!rowptr || !status || (n_edges > 0 && (!edge_index || !entries || !workspace))) return LGC_E_INVAL;
+    if (normalize && !dis_in && (by_source || !dis_out || !deg_out)) return LGC_E_INVAL;
+    hipStream_t stream = as_stream(stream_);
+    const int32_t N = (int32_t)n_nodes, E = (int32_t)n_edges;
+    if (E == 0) {
+        hipError_t err = hipMemsetAsync(rowptr, 0, sizeof(int32_t) * (size_t)(N + 1), stream);
+        if (err == hipSuccess && normalize && !dis_in) {
+            err = hipMemsetAsync(deg_out, 0, sizeof(float) * (size_t)N, stream);
+            if (err == hipSuccess) err = hipMemsetAsync(dis_out, 0, sizeof(float) * (size_t)N, stream);
+        }
+        return (int)err;
+    }
+    BuildWs ws = carve_build_ws(workspace, n_nodes, n_edges);
+    if (workspace_bytes < ws.total) return LGC_E_WORKSPACE;
+    if (!aligned_to(workspace, 256)) return LGC_E_ALIGN;
+
+    const int eb = ceil_div(E, kBlock), nb = ceil_div((long)N + 1, kBlock);
+    hipLaunchKernelGGL(k_build_keys, dim3(eb), dim3(kBlock), 0, stream, edge_index, n_edges, n_nodes,
+                       (int)by_source, ws.keys_in, ws.ids_in, status);
+    size_t cub_bytes = ws.cub_bytes;
+    hipError_t err = hipcub::DeviceRadixSort::SortPairs(ws.cub, cub_bytes, ws.keys_in, ws.keys_out, ws.ids_in,
+                                                        ws.ids_out, E, 0, end_bit_for(n_nodes), stream);
+    if (err != hipSuccess) return (int)err;
+    hipLaunchKernelGGL(k_build_rowptr, dim3(nb), dim3(kBlock), 0, stream, ws.keys_out, E, N, rowptr);
+
+    const float *dis = dis_in;
+    if (normalize && !dis_in) {
+        hipLaunchKernelGGL(k_build_sorted_weight, dim3(eb), dim3(kBlock), 0, stream, ws.ids_out, edge_weight, E,
+                           ws.w_sorted);
+        hipLaunchKernelGGL(k_build_degree_serial, dim3(ceil_div(N, kBlock)), dim3(kBlock), 0, stream, rowptr,
+                           ws.w_sorted, N, deg_out);
+        hipLaunchKernelGGL(k_build_degree_wave, dim3(ceil_div(N, kBlock / kWave)), dim3(kBlock), 0, stream, rowptr,
+                           ws.w_sorted, N, deg_out);
+        hipLaunchKernelGGL(k_build_dis, dim3(ceil_div(N, kBlock)), dim3(kBlock), 0, stream, deg_out, N, dis_out);
+        dis = dis_out;
+    }
+    hipLaunchKernelGGL(k_build_entries, dim3(eb), dim3(kBlock), 0, stream, edge_index, edge_weight, ws.ids_out, dis,
+                       n_edges, n_nodes, (int)by_source, (int)normalize, entries, edge_val);
+    return (int)hipGetLastError();
+}
+
+int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin, int32_t row_end, int32_t short_max,
+             const lgc_chunk *chunks, int32_t n_chunks, const lgc_multi_row *multi, int32_t n_multi, float *partials,
+             const float *x, int64_t x_stride, float *y, int64_t y_stride, const float *r, int64_t r_stride, float a,
+             float b, int32_t dim, void *stream_) {
+    DimCfg cfg;
+    if (!dim_cfg(dim, &cfg)) return LGC_E_DIM;
+    if (!rowptr || !x || !y || row_begin < 0 || row_end < row_begin || n_chunks < 0 || n_multi < 0 || short_max < 0)
+        return LGC_E_INVAL;
+    if ((n_chunks > 0 && !chunks) || (n_multi > 0 && (!multi || !partials))) return LGC_E_INVAL;
+    if (x_stride < dim || y_stride < dim || (r && r_stride < dim)) return LGC_E_INVAL;
+    if (x == y) return LGC_E_INVAL;
+    if (cfg.vec == 4) {
+        const size_t al = cfg.tail ? 8 : 16;
+        const int64_t sm = cfg.tail ? 2 : 4;
+        if (!aligned_to(x, al) || !aligned_to(y, al) || (r && !aligned_to(r, al)) ||
+            (partials && !aligned_to(partials, al)))
+            return LGC_E_ALIGN;
+        if (x_stride % sm || y_stride % sm || (r && r_stride % sm)) return LGC_E_ALIGN;
+    }
+    hipStream_t stream = as_stream(stream_);
+    SpmmArgs p{rowptr, entries, x, y, r, x_stride, y_stride, r_stride, a, b, dim, cfg.lpr, row_begin, row_end, short_max};
+    const int waves_per_block = kBlock / kWave;
+    const int rows_per_wave = kWave / cfg.lpr;
+    return dispatch_dim(cfg, [&](auto vec, auto tail) -> int {
+        constexpr int V = decltype(vec)::value;
+        constexpr bool T = decltype(tail)::value;
+        const int64_t n_rows = (int64_t)row_end - row_begin;
+        if (n_rows > 0) {
+            int blocks = ceil_div(ceil_div(n_rows, rows_per_wave), waves_per_block);
+            hipLaunchKernelGGL((k_spmm_rows<V, T>), dim3(blocks), dim3(kBlock), 0, stream, p);
+        }
+        if (n_chunks > 0) {
+            hipLaunchKernelGGL((k_spmm_chunks<V, T>), dim3(ceil_div(n_chunks, waves_per_block)), dim3(kBlock), 0,
+                               stream, p, chunks, n_chunks, partials);
+        }
+        if (n_multi > 0) {
+            int blocks = ceil_div(ceil_div(n_multi, rows_per_wave), waves_per_block);
+            hipLaunchKernelGGL((k_spmm_combine<V, T>), dim3(blocks), dim3(kBlock), 0, stream, p, multi, n_multi,
+                               partials);
+        }
+        return (int)hipGetLastError();
+    });
+}
+
+int lgc_axpby(float *y, int64_t y_stride, const float *r, int64_t r_stride, float a, float b, int64_t n_rows,
+              int32_t dim, void *stream_) {
+    if (!y || n_rows < 0 || dim < 1 || y_stride < dim || (r && r_stride < dim)) return LGC_E_INVAL;
+    if (n_rows == 0) return 0;
+    int64_t total = n_rows * dim;
+    int blocks = (int)std::min<int64_t>(ceil_div(total, kBlock), 256 * 8);
+    hipLaunchKernelGGL(k_axpby, dim3(blocks), dim3(kBlock), 0, as_stream(stream_), y, y_stride, r, r_stride, a, b,
+                       n_rows, dim);
+    return (int)hipGetLastError();
+}
+
+int lgc_pair_dot(const float *emb, int64_t stride, int32_t dim, int64_t n_nodes, const int64_t *idx0,
+                 const int64_t *idx1, int64_t n_pairs, float *scores, int32_t *status, void *stream_) {
+    if (!emb || !status || dim < 1 || stride < dim || n_nodes < 0 || n_pairs < 0) return LGC_E_INVAL;
+    if (n_pairs == 0) return 0;
+    if (!idx0 || !idx1 || !scores) return LGC_E_INVAL;
+    hipLaunchKernelGGL(k_pair_dot, dim3(ceil_div(n_pairs, kBlock / kWave)), dim3(kBlock), 0, as_stream(stream_), emb,
+                       stride, dim, n_nodes, idx0, idx1, n_pairs, scores, status);
+    return (int)hipGetLastError();
+}
+
+int lgc_pair_dot_backward(const float *grad_scores, const float *emb, int64_t stride, int32_t dim, int64_t n_nodes,
+                          const int64_t *idx0, const int64_t *idx1, int64_t n_pairs, float *grad_emb,
+                          int32_t *status, void *stream_) {
+    if (!emb || !grad_emb || !status || dim < 1 || stride < dim || n_nodes < 0 || n_pairs < 0) return LGC_E_INVAL;
+    if (n_pairs == 0) return 0;
+    if (!idx0 || !idx1 || !grad_scores) return LGC_E_INVAL;
+    hipLaunchKernelGGL(k_pair_dot_bwd, dim3(ceil_div(n_pairs, kBlock / kWave)), dim3(kBlock), 0, as_stream(stream_),
+                       grad_scores, emb, stride, dim, n_nodes, idx0, idx1, n_pairs, grad_emb, status);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,163 @@
+"""Differentiable propagation on the HIP kernels.
+
+``propagate_sum`` computes what src/lightgcn.py:91-99 computes,
+
+    out = sum_{l=0..K} alpha_l * A^l x0 ,
+
+but in Horner form  h_K = alpha_K x0,  h_l = alpha_l x0 + A h_{l+1},  out = h_0 :
+K sparse hops, each with the layer-sum folded into its epilogue (``y = a*(A x) + b*x0``).
+Compared with "propagate, then axpy into a running sum" this removes the K read-modify-write
+sweeps of the [N, D] accumulator -- per hop the only traffic beyond the SpMM
+itself is one read of x0's row.  The value is the same polynomial in A; only the association of
+the fp32 additions differs from the reference (covered by the norm-wise 1e-5 parity gate).
+
+The operator is linear in x0, so the backward pass is the same routine on A^T and needs no
+saved activations:  d out / d x0 = sum_l alpha_l (A^T)^l.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+from torch import Tensor
+from torch.autograd.function import once_differentiable
+
+from . import _native
+from .graph import Operator, PropGraph
+
+
+# bench.py sets this to a list to receive one (start, end) pair of events per hop, recorded on the
+# stream the kernels are launched on; None (the default) records nothing.
+HOP_EVENT_LOG: Optional[list] = None
+
+
+def _timed_apply(op: Operator, x: Tensor, out: Tensor, **kw) -> None:
+    if HOP_EVENT_LOG is None:
+        op.apply(x, out, **kw)
+        return
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    op.apply(x, out, **kw)
+    end.record()
+    HOP_EVENT_LOG.append((start, end))
+
+
+def horner_hops(op: Operator, x0: Tensor, alphas: Sequence[float]) -> Tensor:
+    """sum_l alphas[l] * op^l x0 with len(alphas)-1 launches of ``op.apply``."""
+    k = len(alphas) - 1
+    if k == 0:
+        return x0 * alphas[0]
+    x0 = x0.contiguous()
+    h = torch.empty_like(x0)
+    # first hop reads x0 directly:  h_{K-1} = alpha_K * (A x0) + alpha_{K-1} * x0
+    _timed_apply(op, x0, h, a=alphas[k], r=x0, b=alphas[k - 1])
+    for layer in range(k - 2, -1, -1):
+        nxt = torch.empty_like(x0)
+        _timed_apply(op, h, nxt, a=1.0, r=x0, b=alphas[layer])
+        h = nxt
+    return h
+
+
+class _PropagateSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0: Tensor, graph: PropGraph, alphas: tuple) -> Tensor:
+        ctx.graph, ctx.alphas = graph, alphas
+        return horner_hops(graph.forward_op, x0.detach(), alphas)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out: Tensor):
+        return horner_hops(ctx.graph.transpose_op, grad_out.contiguous(), ctx.alphas), None, None
+
+
+class _Hop(torch.autograd.Function):
+    """One LGConv hop y = A x (the operator surface of src/lightgcn.py:96)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, graph: PropGraph) -> Tensor:
+        ctx.graph = graph
+        x = x.detach().contiguous()
+        return graph.forward_op.apply(x, torch.empty_like(x))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out: Tensor):
+        g = grad_out.contiguous()
+        return ctx.graph.transpose_op.apply(g, torch.empty_like(g)), None
+
+
+def propagate_sum(x0: Tensor, graph: PropGraph, alphas: Sequence[float]) -> Tensor:
+    _native.require_device(x0, "embedding table")
+    return _PropagateSum.apply(x0, graph, tuple(float(a) for a in alphas))
+
+
+def hop(x: Tensor, graph: PropGraph) -> Tensor:
+    _native.require_device(x, "x")
+    return _Hop.apply(x, graph)
+
+
+# ----------------------------------------------------------------------------------------
+# pair scoring
+# ----------------------------------------------------------------------------------------
+_status_words = {}
+
+
+def _status(device: torch.device) -> Tensor:
+    t = _status_words.get(device)
+    if t is None:
+        t = torch.zeros(4, dtype=torch.int32, device=device)
+        _status_words[device] = t
+    return t
+
+
+def check_index_status(device: Optional[torch.device] = None) -> None:
+    """Synchronising check: raise IndexError if any pair-scoring launch since the last check saw an
+    out-of-range label index (the kernels skip such pairs and score them NaN instead of faulting)."""
+    for dev, t in list(_status_words.items()):
+        if device is not None and dev != device:
+            continue
+        if int(t[0].item()) & _native.ST_INDEX_OOB:
+            t.zero_()
+            raise IndexError("edge_label_index contains node ids outside [0, num_nodes)")
+
+
+class _PairDot(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emb: Tensor, idx0: Tensor, idx1: Tensor) -> Tensor:
+        lib = _native.load()
+        emb_c = emb.detach().contiguous()
+        idx0, idx1 = idx0.contiguous(), idx1.contiguous()
+        scores = torch.empty(idx0.numel(), dtype=torch.float32, device=emb.device)
+        with torch.cuda.device(emb.device):
+            code = lib.lgc_pair_dot(_native.ptr(emb_c), emb_c.stride(0), emb_c.size(1), emb_c.size(0),
+                                    _native.ptr(idx0), _native.ptr(idx1), idx0.numel(), _native.ptr(scores),
+                                    _native.ptr(_status(emb.device)), _native.stream_of(emb.device))
+        _native.check(code, "lgc_pair_dot")
+        ctx.save_for_backward(emb_c, idx0, idx1)
+        return scores
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_scores: Tensor):
+        lib = _native.load()
+        emb, idx0, idx1 = ctx.saved_tensors
+        grad = torch.zeros_like(emb)
+        gs = grad_scores.contiguous()
+        with torch.cuda.device(emb.device):
+            code = lib.lgc_pair_dot_backward(_native.ptr(gs), _native.ptr(emb), emb.stride(0), emb.size(1),
+                                             emb.size(0), _native.ptr(idx0), _native.ptr(idx1), idx0.numel(),
+                                             _native.ptr(grad), _native.ptr(_status(emb.device)),
+                                             _native.stream_of(emb.device))
+        _native.check(code, "lgc_pair_dot_backward")
+        return grad, None, None
+
+
+def pair_dot(emb: Tensor, edge_label_index: Tensor) -> Tensor:
+    """scores[m] = <emb[idx[0, m]], emb[idx[1, m]]>  (src/lightgcn.py:123-125)."""
+    _native.require_device(emb, "embeddings")
+    _native.require_device(edge_label_index, "edge_label_index")
+    if edge_label_index.dtype != torch.int64 or edge_label_index.dim() != 2 or edge_label_index.size(0) != 2:
+        raise TypeError("edge_label_index must be an int64 tensor of shape [2, M]")
+    if emb.dtype != torch.float32 or emb.dim() != 2:
+        raise TypeError("embeddings must be a 2-D fp32 tensor")
+    return _PairDot.apply(emb, edge_label_index[0], edge_label_index[1])

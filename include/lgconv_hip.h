@@ -1,0 +1,159 @@
+/*
+ * lgconv_hip.h -- C ABI of the MI355X (gfx950) LightGCN propagation library.
+ *
+ * This is the drop-in boundary for the hot path of happykygo/GNN-eCommerce
+ * (BASELINE.json: north_star).  The reference has no FFI of its own: the path is reached
+ * through two Python call surfaces.  Each entry point below names
+ * the reference interface it stands in for (paths relative to the reference tree); the
+ * ctypes stubs a maintainer would add are in INTEGRATION.md and are what
+ * gnn-ecommerce_amd/_native.py contains.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless it says host
+ *   - all buffers are owned by the caller (PyTorch's caching allocator in practice); the
+ *     library borrows them for the duration of the launches it enqueues, keeps no global
+ *     state and allocates nothing
+ *   - every function enqueues on `stream` (a hipStream_t passed as void*) and returns
+ *     without synchronising
+ *   - return value: 0 = ok; >0 = hipError_t from the runtime; <0 = LGC_E_* argument error
+ *   - `status` words are device int32 the kernels OR error bits into (LGC_ST_*); the
+ *     caller zeroes them and reads them back when it wants to know
+ *   - values fp32, indices int32 inside the library; the reference's int64 COO is converted
+ *     by lgc_build_csr
+ */
+#ifndef LGCONV_HIP_H
+#define LGCONV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LGC_ABI_VERSION 1
+
+/* argument errors (negative return values) */
+#define LGC_E_INVAL      (-1)  /* null pointer, negative size, bad flag                    */
+#define LGC_E_DIM        (-2)  /* embedding width not supported (1..256, see lgc_dim_ok)   */
+#define LGC_E_WORKSPACE  (-3)  /* workspace smaller than lgc_build_workspace_bytes()        */
+#define LGC_E_RANGE      (-4)  /* node or edge count does not fit int32                     */
+#define LGC_E_ALIGN      (-5)  /* pointer / stride alignment requirement violated           */
+
+/* bits OR-ed into device status words */
+#define LGC_ST_INDEX_OOB 1     /* an index was outside [0, n_nodes); that element was skipped */
+
+/* One adjacency entry as the kernels read it: 8 bytes, {source column, fp32 value}. */
+typedef struct lgc_entry {
+    int32_t col;
+    float   val;
+} lgc_entry;
+
+/* One unit of work for rows longer than `short_max` (see lgc_spmm). */
+typedef struct lgc_chunk {
+    int32_t row;    /* output row                                                   */
+    int32_t begin;  /* first entry (index into entries[])                            */
+    int32_t end;    /* one past the last entry                                       */
+    int32_t slot;   /* >=0: write the raw sum to partials[slot]; -1: finish the row  */
+} lgc_chunk;
+
+/* A row that was cut into several chunks: its partial sums sit in slots [begin, end). */
+typedef struct lgc_multi_row {
+    int32_t row;
+    int32_t slot_begin;
+    int32_t slot_end;
+    int32_t reserved;
+} lgc_multi_row;
+
+int lgc_abi_version(void);
+
+/* Human-readable text for a negative return code (host pointer, static storage). */
+const char *lgc_error_string(int code);
+
+/* 1 if lgc_spmm / lgc_pair_dot accept this embedding width. */
+int lgc_dim_ok(int32_t dim);
+
+/* ---------------------------------------------------------------------------------------
+ * Graph build: dense COO -> CSR with normalised values.
+ *
+ * Replaces what PyG's LGConv.forward -> gcn_norm recomputes on every layer of every call
+ * (called from src/lightgcn.py:96; COO produced by src/utils_v2.py:146-165, copy at
+ * torchserve/lightgcn_handler.py:112-131).
+ *
+ *   edge_index  int64 [2, n_edges] contiguous: row 0 = source j, row 1 = target i
+ *   edge_weight fp32 [n_edges] or NULL (= all ones, as upstream)
+ *   by_source   0: rows of the CSR are targets, columns sources  (the forward operator A)
+ *               1: rows are sources, columns targets              (A^T, for the backward pass)
+ *   normalize   1: val = dis[j] * w * dis[i], dis = deg^-1/2 (inf -> 0), deg = weighted
+ *                  in-degree by target accumulated SEQUENTIALLY IN EDGE ORDER in fp32 --
+ *                  the order the reference's CPU scatter uses
+ *               0: val = w
+ *   dis_in      normalize=1 only: NULL -> compute deg/dis here (requires by_source=0) and
+ *               write them to deg_out/dis_out; non-NULL -> use these (the A^T build)
+ *   rowptr      out int32 [n_nodes + 1]
+ *   entries     out lgc_entry [n_edges]; inside a row the entries keep the edge order
+ *   edge_val    out fp32 [n_edges] in ORIGINAL edge order, or NULL
+ *   deg_out, dis_out  out fp32 [n_nodes] or NULL
+ * ------------------------------------------------------------------------------------- */
+size_t lgc_build_workspace_bytes(int64_t n_nodes, int64_t n_edges);
+
+int lgc_build_csr(const int64_t *edge_index, const float *edge_weight,
+                  int64_t n_nodes, int64_t n_edges,
+                  int32_t by_source, int32_t normalize,
+                  const float *dis_in,
+                  int32_t *rowptr, lgc_entry *entries,
+                  float *edge_val, float *deg_out, float *dis_out,
+                  void *workspace, size_t workspace_bytes,
+                  int32_t *status, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * One propagation hop:  y[row] = a * sum_k entries[k].val * x[entries[k].col] + b * r[row]
+ * for row in [row_begin, row_end) and for the rows named by `chunks`.
+ *
+ * Replaces one LGConv.forward (src/lightgcn.py:96) and, through a/b/r, the layer sum of
+ * src/lightgcn.py:93,97 folded into the epilogue (r may be NULL: then y = a * sum).
+ *
+ *   rows with at most `short_max` entries in [row_begin,row_end) are done by one lane group
+ *   each, accumulating in entry order; longer rows there are skipped and must appear in
+ *   `chunks` (one wavefront per chunk).  Chunks with slot >= 0 write raw sums to
+ *   partials[slot * dim ...]; `multi` rows then add their slots in order and apply the
+ *   epilogue, which makes the result independent of scheduling.
+ *
+ *   x, y, r     fp32, row strides in floats; x/y/r rows must be 8-byte aligned, 16-byte when
+ *               dim % 4 == 0;  y must not alias x
+ *   partials    fp32 [n_slots, dim] or NULL when no chunk has slot >= 0
+ * ------------------------------------------------------------------------------------- */
+int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries,
+             int32_t row_begin, int32_t row_end, int32_t short_max,
+             const lgc_chunk *chunks, int32_t n_chunks,
+             const lgc_multi_row *multi, int32_t n_multi, float *partials,
+             const float *x, int64_t x_stride,
+             float *y, int64_t y_stride,
+             const float *r, int64_t r_stride,
+             float a, float b, int32_t dim, void *stream);
+
+/* y[i, :dim] = a * y[i, :dim] + b * r[i, :dim]  for i < n_rows (epilogue after an exchange). */
+int lgc_axpby(float *y, int64_t y_stride, const float *r, int64_t r_stride,
+              float a, float b, int64_t n_rows, int32_t dim, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Pair scoring: scores[m] = <emb[idx0[m]], emb[idx1[m]]>.
+ * Replaces src/lightgcn.py:123-125.  idx are the rows of edge_label_index
+ * (src/utils_v2.py:184-190), int64.  Out-of-range pairs score NaN and set LGC_ST_INDEX_OOB.
+ * ------------------------------------------------------------------------------------- */
+int lgc_pair_dot(const float *emb, int64_t stride, int32_t dim, int64_t n_nodes,
+                 const int64_t *idx0, const int64_t *idx1, int64_t n_pairs,
+                 float *scores, int32_t *status, void *stream);
+
+/* Gradient seed of lgc_pair_dot (what autograd builds at src/train_lightgcn.py:146):
+ *   grad_emb[idx0[m]] += g[m] * emb[idx1[m]];  grad_emb[idx1[m]] += g[m] * emb[idx0[m]]
+ * grad_emb [n_nodes, stride] must be zero-filled by the caller; accumulation uses fp32 atomics. */
+int lgc_pair_dot_backward(const float *grad_scores, const float *emb, int64_t stride,
+                          int32_t dim, int64_t n_nodes,
+                          const int64_t *idx0, const int64_t *idx1, int64_t n_pairs,
+                          float *grad_emb, int32_t *status, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LGCONV_HIP_H */

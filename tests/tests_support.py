@@ -1,0 +1,35 @@
+"""Input generators shared by tests/golden/make_golden.py and the tests (no reference code here)."""
+import numpy as np
+import torch
+
+WEIGHT_SET = np.array([0.01, 0.02, 0.03, 0.1, 0.11, 0.5, 1.0], dtype=np.float32)
+
+
+def formula_weight(n, dim):
+    """Exactly representable fp32 table, no RNG."""
+    r = np.arange(n, dtype=np.int64)[:, None]
+    c = np.arange(dim, dtype=np.int64)[None, :]
+    return (((r * 131 + c * 17 + (r * c) % 29) % 257) - 128).astype(np.float32) / 1024.0
+
+
+def hub_pairs(seed, n_users, n_items):
+    """(user, item, weight): item 0 is linked to ~90 % of the users (degree > 1e4 at n_users=12000)."""
+    rng = np.random.default_rng(seed)
+    u_hub = np.arange(n_users)[rng.random(n_users) < 0.9]
+    rest_u = rng.integers(n_users, size=20000)
+    rest_i = rng.integers(1, n_items, size=20000)
+    keys = np.unique(np.concatenate([u_hub * n_items, rest_u * n_items + rest_i]))
+    keys = np.concatenate([keys, np.setdiff1d(np.arange(n_users) * n_items + 1, keys)])  # cover all users
+    rng.shuffle(keys)
+    u, i = keys // n_items, keys % n_items
+    w = WEIGHT_SET[rng.integers(len(WEIGHT_SET), size=len(keys))]
+    return u, i, w
+
+
+def hub_inputs(seed, n_users, n_items, dim):
+    """edge_index / edge_weight in the reference's COO layout (src/utils_v2.py:146-165) + formula table."""
+    u, i, w = hub_pairs(seed, n_users, n_items)
+    u_t, i_t, w_t = torch.from_numpy(u), torch.from_numpy(i + n_users), torch.from_numpy(w)
+    ei = torch.stack((torch.cat([u_t, i_t]), torch.cat([i_t, u_t])))
+    ew = torch.cat([w_t, w_t])
+    return ei, ew, torch.from_numpy(formula_weight(n_users + n_items, dim))
