@@ -112,7 +112,7 @@ __global__ void k_build_dis(const float *__restrict__ deg, int32_t n_nodes, floa
     int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_nodes) return;
     // deg^-1/2 as 1/sqrt with both steps correctly rounded; +inf (deg == 0) -> 0, NaN (deg < 0) stays.
-    float d = __fdiv_rn(1.0f, __fsqrt_rn(deg[r]));
+    float d = 1.0f / sqrtf(deg[r]);  // hipcc default: both correctly rounded (NOT __fsqrt_rn = bare v_sqrt_f32, 1 ulp)
     dis[r] = (d == INFINITY) ? 0.0f : d;
 }
 
