@@ -31,6 +31,7 @@ import torch
 import torch.distributed as dist
 
 LAYERS, DIM, SEED = 3, 64, 0
+CPU_THREADS_DEFAULT = 32  # fastest setting measured on the GPU box's 2 x EPYC 9575F host
 HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
 
 
@@ -43,15 +44,17 @@ def parse():
     ap.add_argument("--dim", type=int, default=DIM)
     ap.add_argument("--config", choices=["cosmetics", "small"], default="cosmetics")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = auto)")
     return ap.parse_args()
 
 
-def cpu_baseline(graph, layers, dim):
+def cpu_baseline(graph, layers, dim, threads=0):
     """Reference-semantics CPU path on a bounded sample: ONE full K-layer propagate of the same graph
     after a one-layer warm-up (about 4 layer-times of CPU work)."""
     from oracle import lightgcn_oracle as oracle
     from gnn_ecommerce_amd import synth
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    cores = threads if threads > 0 else min(avail, CPU_THREADS_DEFAULT)
     torch.set_num_threads(cores)
     ei, ew = graph.coo()
     w0 = synth.xavier_table(graph.num_nodes, dim, SEED)
@@ -160,7 +163,7 @@ def main():
                          "launches_timed": len(hop_ms)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(graph, args.layers, args.dim)
+            line["cpu_baseline"] = cpu_baseline(graph, args.layers, args.dim, args.cpu_threads)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

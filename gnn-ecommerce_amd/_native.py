@@ -15,7 +15,8 @@ from typing import Optional
 import torch
 
 LIB_NAME = "liblgconv_hip.so"
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", LIB_NAME)
+# LGCN_LIB_PATH selects another build of the SAME library (A/B kernel experiments); never a fallback.
+LIB_PATH = os.environ.get("LGCN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", LIB_NAME)
 ABI_VERSION = 1
 
 # status bits (include/lgconv_hip.h)

@@ -215,6 +215,84 @@ __device__ __forceinline__ Acc<VEC> load_row(const float *p, int nvalid) {
     return o;
 }
 
+// Streaming variants for data touched exactly once per hop (CSR entries, the epilogue row, the
+// output): non-temporal hints keep them from evicting the gathered rows -- the only data with
+// reuse -- out of the 4 MiB per-XCD L2.
+#ifndef LGC_NT
+#define LGC_NT 0  // measured on MI355X: nt hints cost 2.4 % on the full-size hop (842 vs 822 us)
+#endif
+template <typename T>
+__device__ __forceinline__ T stream_load(const T *p) {
+#if LGC_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+template <typename T>
+__device__ __forceinline__ void stream_store(T *p, T v) {
+#if LGC_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ f4 stream_load_f4(const float *p) {
+#if LGC_NT
+    return __builtin_nontemporal_load(reinterpret_cast<const f4u *>(p));
+#else
+    return *reinterpret_cast<const f4u *>(p);
+#endif
+}
+__device__ __forceinline__ void stream_store_f4(float *p, f4 v) {
+#if LGC_NT
+    __builtin_nontemporal_store(v, reinterpret_cast<f4u *>(p));
+#else
+    *reinterpret_cast<f4u *>(p) = v;
+#endif
+}
+__device__ __forceinline__ lgc_entry load_entry(const lgc_entry *p) {
+    typedef int i2 __attribute__((ext_vector_type(2)));
+    i2 t = stream_load(reinterpret_cast<const i2 *>(p));
+    lgc_entry e;
+    e.col = t.x;
+    e.val = __int_as_float(t.y);
+    return e;
+}
+
+template <int VEC, bool TAIL>
+__device__ __forceinline__ Acc<VEC> load_row_stream(const float *p, int nvalid) {
+    Acc<VEC> o;
+    if constexpr (VEC == 4) {
+        if (!TAIL || nvalid == 4) {
+            f4 t = stream_load_f4(p);
+            o.v[0] = t.x; o.v[1] = t.y; o.v[2] = t.z; o.v[3] = t.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o.v[i] = i < nvalid ? stream_load(p + i) : 0.0f;
+        }
+    } else {
+        o.v[0] = stream_load(p);
+    }
+    return o;
+}
+
+template <int VEC, bool TAIL>
+__device__ __forceinline__ void store_row_stream(float *p, const Acc<VEC> &o, int nvalid) {
+    if constexpr (VEC == 4) {
+        if (!TAIL || nvalid == 4) {
+            f4 t = {o.v[0], o.v[1], o.v[2], o.v[3]};
+            stream_store_f4(p, t);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < nvalid) stream_store(p + i, o.v[i]);
+        }
+    } else {
+        stream_store(p, o.v[0]);
+    }
+}
+
 template <int VEC, bool TAIL>
 __device__ __forceinline__ void store_row(float *p, const Acc<VEC> &o, int nvalid) {
     if constexpr (VEC == 4) {
@@ -246,13 +324,16 @@ __device__ __forceinline__ void epilogue_store(const SpmmArgs &p, int64_t row, i
         for (int i = 0; i < VEC; ++i) acc.v[i] = __fmul_rn(p.a, acc.v[i]);
     }
     if (p.r != nullptr) {
-        Acc<VEC> rv = load_row<VEC, TAIL>(p.r + row * p.r_stride + c0, nvalid);
+        Acc<VEC> rv = load_row_stream<VEC, TAIL>(p.r + row * p.r_stride + c0, nvalid);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc.v[i] = __fadd_rn(acc.v[i], __fmul_rn(p.b, rv.v[i]));
     }
-    store_row<VEC, TAIL>(p.y + row * p.y_stride + c0, acc, nvalid);
+    store_row_stream<VEC, TAIL>(p.y + row * p.y_stride + c0, acc, nvalid);
 }
 
+#ifndef LGC_EARLY_R
+#define LGC_EARLY_R 1  // measured: issuing the epilogue row load ahead of the gathers = -3 % per hop
+#endif
 // Short rows: one lane group per row, entries in order, 4 gathers in flight per group.
 template <int VEC, bool TAIL>
 __global__ __launch_bounds__(kBlock) void k_spmm_rows(SpmmArgs p) {
@@ -273,9 +354,13 @@ __global__ __launch_bounds__(kBlock) void k_spmm_rows(SpmmArgs p) {
     const lgc_entry *__restrict__ ent = p.entries;
     Acc<VEC> acc;
     acc.zero();
+#if LGC_EARLY_R
+    Acc<VEC> rv;
+    if (p.r != nullptr) rv = load_row<VEC, TAIL>(p.r + row * p.r_stride + c0, nvalid);
+#endif
     int32_t k = s;
     for (; k + 4 <= e; k += 4) {
-        lgc_entry e0 = ent[k], e1 = ent[k + 1], e2 = ent[k + 2], e3 = ent[k + 3];
+        lgc_entry e0 = load_entry(ent + k), e1 = load_entry(ent + k + 1), e2 = load_entry(ent + k + 2), e3 = load_entry(ent + k + 3);
         Acc<VEC> x0 = load_row<VEC, TAIL>(xb + (int64_t)e0.col * p.x_stride, nvalid);
         Acc<VEC> x1 = load_row<VEC, TAIL>(xb + (int64_t)e1.col * p.x_stride, nvalid);
         Acc<VEC> x2 = load_row<VEC, TAIL>(xb + (int64_t)e2.col * p.x_stride, nvalid);
@@ -286,11 +371,23 @@ __global__ __launch_bounds__(kBlock) void k_spmm_rows(SpmmArgs p) {
         mul_add<VEC>(acc, e3.val, x3);
     }
     for (; k < e; ++k) {
-        lgc_entry e0 = ent[k];
+        lgc_entry e0 = load_entry(ent + k);
         Acc<VEC> x0 = load_row<VEC, TAIL>(xb + (int64_t)e0.col * p.x_stride, nvalid);
         mul_add<VEC>(acc, e0.val, x0);
     }
+#if LGC_EARLY_R
+    if (p.a != 1.0f) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc.v[i] = __fmul_rn(p.a, acc.v[i]);
+    }
+    if (p.r != nullptr) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc.v[i] = __fadd_rn(acc.v[i], __fmul_rn(p.b, rv.v[i]));
+    }
+    store_row<VEC, TAIL>(p.y + row * p.y_stride + c0, acc, nvalid);
+#else
     epilogue_store<VEC, TAIL>(p, row, c0, nvalid, acc);
+#endif
 }
 
 // Long rows: one wavefront per chunk.  Lane group g takes entries begin+g, begin+g+G, ...;
@@ -316,7 +413,7 @@ __global__ __launch_bounds__(kBlock) void k_spmm_chunks(SpmmArgs p, const lgc_ch
         const lgc_entry *__restrict__ ent = p.entries;
         int32_t k = ch.begin + g;
         for (; k + 3 * groups < ch.end; k += 4 * groups) {
-            lgc_entry e0 = ent[k], e1 = ent[k + groups], e2 = ent[k + 2 * groups], e3 = ent[k + 3 * groups];
+            lgc_entry e0 = load_entry(ent + k), e1 = load_entry(ent + k + groups), e2 = load_entry(ent + k + 2 * groups), e3 = load_entry(ent + k + 3 * groups);
             Acc<VEC> x0 = load_row<VEC, TAIL>(xb + (int64_t)e0.col * p.x_stride, nvalid);
             Acc<VEC> x1 = load_row<VEC, TAIL>(xb + (int64_t)e1.col * p.x_stride, nvalid);
             Acc<VEC> x2 = load_row<VEC, TAIL>(xb + (int64_t)e2.col * p.x_stride, nvalid);
@@ -327,7 +424,7 @@ __global__ __launch_bounds__(kBlock) void k_spmm_chunks(SpmmArgs p, const lgc_ch
             mul_add<VEC>(acc, e3.val, x3);
         }
         for (; k < ch.end; k += groups) {
-            lgc_entry e0 = ent[k];
+            lgc_entry e0 = load_entry(ent + k);
             Acc<VEC> x0 = load_row<VEC, TAIL>(xb + (int64_t)e0.col * p.x_stride, nvalid);
             mul_add<VEC>(acc, e0.val, x0);
         }
@@ -348,27 +445,50 @@ __global__ __launch_bounds__(kBlock) void k_spmm_chunks(SpmmArgs p, const lgc_ch
     }
 }
 
+// Rows cut into several chunks: one wavefront per row.  Lane group g adds slots g, g+G, g+2G, ...
+// (4 loads in flight per group), then the G group sums are added in group order -- a fixed
+// association, so the result does not depend on scheduling.
 template <int VEC, bool TAIL>
 __global__ __launch_bounds__(kBlock) void k_spmm_combine(SpmmArgs p, const lgc_multi_row *__restrict__ multi,
                                                         int32_t n_multi, const float *__restrict__ partials) {
     const int lane = threadIdx.x & (kWave - 1);
-    const int rows_per_wave = kWave / p.lpr;
+    const int64_t m = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x / kWave);
+    if (m >= n_multi) return;  // wave-uniform
+    const lgc_multi_row mr = multi[m];
+    const int groups = kWave / p.lpr;
     const int g = lane / p.lpr;
     const int l = lane - g * p.lpr;
-    const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x / kWave);
-    const int64_t m = wave * rows_per_wave + g;
     const int c0 = l * VEC;
     const int nvalid = min(VEC, p.dim - c0);
-    if (g >= rows_per_wave || m >= n_multi || nvalid <= 0) return;
-    const lgc_multi_row mr = multi[m];
+    const bool active = g < groups && nvalid > 0;
     Acc<VEC> acc;
     acc.zero();
-    for (int32_t s = mr.slot_begin; s < mr.slot_end; ++s) {
-        Acc<VEC> t = load_row<VEC, TAIL>(partials + (int64_t)s * p.dim + c0, nvalid);
+    if (active) {
+        const float *pb = partials + c0;
+        int32_t s = mr.slot_begin + g;
+        for (; s + 3 * groups < mr.slot_end; s += 4 * groups) {
+            Acc<VEC> t0 = load_row<VEC, TAIL>(pb + (int64_t)s * p.dim, nvalid);
+            Acc<VEC> t1 = load_row<VEC, TAIL>(pb + (int64_t)(s + groups) * p.dim, nvalid);
+            Acc<VEC> t2 = load_row<VEC, TAIL>(pb + (int64_t)(s + 2 * groups) * p.dim, nvalid);
+            Acc<VEC> t3 = load_row<VEC, TAIL>(pb + (int64_t)(s + 3 * groups) * p.dim, nvalid);
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) acc.v[i] = __fadd_rn(acc.v[i], t.v[i]);
+            for (int i = 0; i < VEC; ++i)
+                acc.v[i] = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(acc.v[i], t0.v[i]), t1.v[i]), t2.v[i]), t3.v[i]);
+        }
+        for (; s < mr.slot_end; s += groups) {
+            Acc<VEC> t0 = load_row<VEC, TAIL>(pb + (int64_t)s * p.dim, nvalid);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc.v[i] = __fadd_rn(acc.v[i], t0.v[i]);
+        }
     }
-    epilogue_store<VEC, TAIL>(p, mr.row, c0, nvalid, acc);
+    for (int j = 1; j < groups; ++j) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float other = __shfl_down(acc.v[i], j * p.lpr);
+            if (g == 0) acc.v[i] = __fadd_rn(acc.v[i], other);
+        }
+    }
+    if (active && g == 0) epilogue_store<VEC, TAIL>(p, mr.row, c0, nvalid, acc);
 }
 
 __global__ void k_axpby(float *__restrict__ y, int64_t y_stride, const float *__restrict__ r, int64_t r_stride,
@@ -583,7 +703,7 @@ int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin,
                                stream, p, chunks, n_chunks, partials);
         }
         if (n_multi > 0) {
-            int blocks = ceil_div(ceil_div(n_multi, rows_per_wave), waves_per_block);
+            int blocks = ceil_div(n_multi, waves_per_block);
             hipLaunchKernelGGL((k_spmm_combine<V, T>), dim3(blocks), dim3(kBlock), 0, stream, p, multi, n_multi,
                                partials);
         }
