@@ -1,0 +1,263 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/lgconv_hip.h declares
+(no compute calls -- there is no GPU here), argument validation that happens before any launch, and the
+host-side logic (work plan, user-range partition, synthetic-graph generator)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+import gnn_ecommerce_amd as lg
+from gnn_ecommerce_amd import _native, synth
+from gnn_ecommerce_amd.graph import build_row_plan
+from gnn_ecommerce_amd.partition import balanced_user_ranges, check_bipartite
+
+HEADER = os.path.join(ROOT, "include", "lgconv_hip.h")
+
+
+def declared_symbols():
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(lgc_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound():
+    lib = _native.load()
+    names = declared_symbols()
+    assert names == sorted(_native.SIGNATURES), "ctypes table and header must list the same entry points"
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert lib.lgc_abi_version() == _native.ABI_VERSION
+    header_version = int(re.search(r"#define LGC_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
+    assert header_version == _native.ABI_VERSION
+
+
+def test_no_torch_types_in_the_abi():
+    code = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)            # declarations only, comments stripped
+    assert "torch" not in code.lower() and "at::" not in code and "hip/" not in code and "Tensor" not in code
+    assert set(re.findall(r"#include <(.*?)>", code)) == {"stddef.h", "stdint.h"}
+
+
+def test_library_links_one_hip_runtime_and_no_torch():
+    out = os.popen(f"readelf -d {_native.LIB_PATH}").read()
+    needed = re.findall(r"NEEDED.*\[(.*?)\]", out)
+    assert any("amdhip64" in n for n in needed)
+    assert not any("torch" in n or "c10" in n for n in needed)
+    assert len([p for p in _native.runtime_libraries() if "libamdhip64" in p]) == 1
+
+
+def test_error_strings_and_dim_support():
+    lib = _native.load()
+    assert lib.lgc_error_string(0) == b"ok"
+    for code in (-1, -2, -3, -4, -5):
+        assert lib.lgc_error_string(code) not in (b"ok", b"unknown error")
+    for dim in (1, 7, 16, 63, 64, 80, 90, 96, 128, 130, 256):
+        assert lib.lgc_dim_ok(dim) == 1
+    for dim in (0, -4, 65, 129, 257, 300):          # odd widths above 64 and anything above 256
+        assert lib.lgc_dim_ok(dim) == 0
+    assert lib.lgc_build_workspace_bytes(1000, 5000) >= 4 * 5000 * 4
+    assert lib.lgc_build_workspace_bytes(10, 2 ** 31) == 0          # does not fit int32
+
+
+def test_argument_errors_are_reported_before_any_launch():
+    lib = _native.load()
+    one = ctypes.c_void_p(16)            # never dereferenced: every call below must fail validation first
+    assert lib.lgc_spmm(one, one, 0, 4, 32, None, 0, None, 0, None, one, 64, ctypes.c_void_p(32), 64, None, 0,
+                        1.0, 0.0, 300, None) == -2                                      # LGC_E_DIM
+    assert lib.lgc_spmm(one, one, 0, 4, 32, None, 0, None, 0, None, one, 64, one, 64, None, 0,
+                        1.0, 0.0, 64, None) == -1                                       # y aliases x
+    assert lib.lgc_spmm(one, one, 0, 4, 32, None, 0, None, 0, None, ctypes.c_void_p(20), 64, ctypes.c_void_p(32), 64,
+                        None, 0, 1.0, 0.0, 64, None) == -5                              # misaligned x
+    assert lib.lgc_spmm(one, one, 0, 4, 32, None, 3, None, 0, None, one, 64, ctypes.c_void_p(32), 64, None, 0,
+                        1.0, 0.0, 64, None) == -1                                       # chunks missing
+    assert lib.lgc_build_csr(one, None, -1, 5, 0, 1, None, one, one, None, one, one, one, 1 << 20, one, None) == -1
+    assert lib.lgc_build_csr(one, None, 10, 5, 1, 1, None, one, one, None, one, one, one, 1 << 20, one, None) == -1
+    assert lib.lgc_build_csr(one, None, 10, 5, 0, 1, None, one, one, None, one, one, ctypes.c_void_p(256), 8, one,
+                             None) == -3                                                # workspace too small
+    assert lib.lgc_pair_dot(one, 8, 64, 10, one, one, 4, one, one, None) == -1          # stride < dim
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "liblgconv_hip.so"))
+    with pytest.raises(_native.NativeLibraryError, match="no CPU or PyTorch fallback"):
+        _native.load()
+
+
+def test_cpu_tensors_are_refused_everywhere():
+    model = lg.LightGCN(12, 64, 2)
+    ei = torch.tensor([[0, 5], [5, 0]])
+    with pytest.raises(_native.NativeLibraryError):
+        model.get_embedding(ei, None)
+    with pytest.raises(_native.NativeLibraryError):
+        model(ei)
+    with pytest.raises(_native.NativeLibraryError):
+        lg.LGConv()(torch.zeros(12, 64), ei)
+    with pytest.raises(_native.NativeLibraryError):
+        lg.pair_dot(torch.zeros(12, 64), ei)
+
+
+def test_model_surface_matches_the_reference_contract():
+    """constructor, attributes, parameters(), state_dict keys, alpha handling, repr."""
+    m = lg.LightGCN(100, 90, 5)
+    assert [k for k, _ in m.state_dict().items()] == ["alpha", "embedding.weight"]
+    assert [tuple(p.shape) for p in m.parameters()] == [(100, 90)]
+    assert torch.allclose(m.alpha, torch.full((6,), 1 / 6)) and len(m.convs) == 5
+    assert all(len(list(c.parameters())) == 0 for c in m.convs)
+    assert repr(m) == "LightGCN(100, 90, num_layers=5)"
+    assert torch.equal(lg.LightGCN(10, 8, 2, alpha=0.3).alpha, torch.tensor([0.3, 0.3, 0.3]))
+    a = torch.tensor([0.5, 0.25, 0.25])
+    assert torch.equal(lg.LightGCN(10, 8, 2, alpha=a).alpha, a)
+    with pytest.raises(AssertionError):
+        lg.LightGCN(10, 8, 2, alpha=torch.ones(2))
+    assert lg.LightGCN(10, 8, 1, normalize=False).convs[0].normalize is False
+    with pytest.raises(TypeError):
+        m.recommend(torch.zeros(2, 2, dtype=torch.long))         # upstream's broken method stays broken
+    sd = {"alpha": torch.full((6,), 0.1), "embedding.weight": torch.zeros(100, 90)}
+    m.load_state_dict(sd)
+    bound = (6 / (100 + 90)) ** 0.5
+    m.reset_parameters()
+    assert m.embedding.weight.abs().max() <= bound and m.embedding.weight.std() > 0
+
+
+def test_losses_match_oracle_on_cpu():
+    """BPRLoss / link_pred_loss are plain torch and device-agnostic."""
+    from oracle import lightgcn_oracle as oracle
+    g = torch.Generator().manual_seed(0)
+    pos, neg, par = torch.randn(64, generator=g), torch.randn(64, generator=g), torch.randn(30, 8, generator=g)
+    assert torch.equal(lg.BPRLoss()(pos, neg), oracle.bpr_loss(pos, neg))
+    assert torch.equal(lg.BPRLoss(1e-4)(pos, neg, par), oracle.bpr_loss(pos, neg, par, 1e-4))
+    m = lg.LightGCN(30, 8, 1)
+    assert torch.equal(m.recommendation_loss(pos, neg, 0), oracle.bpr_loss(pos, neg))
+    y = (torch.rand(64, generator=g) > 0.5)
+    assert torch.allclose(m.link_pred_loss(pos, y), torch.nn.functional.binary_cross_entropy_with_logits(pos, y.float()))
+
+
+# ---------------------------------------------------------------------------------------------
+# work plan
+# ---------------------------------------------------------------------------------------------
+def check_plan(rowptr, lo, hi, short_max, chunk_len):
+    plan = build_row_plan(rowptr, lo, hi, short_max, chunk_len)
+    deg = (rowptr[1:] - rowptr[:-1]).long()
+    covered = torch.zeros(int(rowptr[-1]), dtype=torch.int64)
+    rows_seen = {}
+    for row, b, e, slot in plan.chunks.tolist():
+        assert lo <= row < hi and deg[row] > short_max
+        assert rowptr[row] <= b < e <= rowptr[row + 1] and e - b <= chunk_len
+        covered[b:e] += 1
+        rows_seen.setdefault(row, []).append((b, e, slot))
+    for row in range(lo, hi):
+        if deg[row] > short_max:
+            parts = rows_seen[row]
+            assert parts[0][0] == rowptr[row] and parts[-1][1] == rowptr[row + 1]
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(len(parts) - 1))      # contiguous, in order
+            if len(parts) == 1:
+                assert parts[0][2] == -1
+            else:
+                slots = [p[2] for p in parts]
+                assert slots == list(range(slots[0], slots[0] + len(parts)))
+            s, e = int(rowptr[row]), int(rowptr[row + 1])
+            assert (covered[s:e] == 1).all()
+        else:
+            assert row not in rows_seen
+    multi = {r: (sb, se) for r, sb, se, _ in plan.multi.tolist()}
+    assert set(multi) == {r for r, p in rows_seen.items() if len(p) > 1}
+    for r, (sb, se) in multi.items():
+        assert [p[2] for p in rows_seen[r]] == list(range(sb, se))
+    assert plan.n_slots == sum(se - sb for sb, se in multi.values())
+    all_slots = sorted(s for p in rows_seen.values() for _, _, s in p if s >= 0)
+    assert all_slots == list(range(plan.n_slots))
+    return plan
+
+
+@pytest.mark.parametrize("short_max,chunk_len", [(0, 1), (0, 5), (3, 4), (32, 256), (10 ** 6, 256)])
+def test_row_plan_covers_every_long_row_exactly_once(short_max, chunk_len):
+    rng = np.random.default_rng(0)
+    deg = np.concatenate([rng.integers(0, 8, 200), [0, 0, 1, 1000, 257, 256, 255, 33, 32], rng.integers(0, 90, 50)])
+    rowptr = torch.from_numpy(np.concatenate([[0], np.cumsum(deg)])).int()
+    n = len(deg)
+    check_plan(rowptr, 0, n, short_max, chunk_len)
+    check_plan(rowptr, 37, n - 11, short_max, chunk_len)
+    empty = check_plan(rowptr, 5, 5, short_max, chunk_len)
+    assert empty.n_chunks == 0 and empty.n_multi == 0
+
+
+def test_row_plan_rejects_bad_parameters():
+    rowptr = torch.tensor([0, 3, 9], dtype=torch.int32)
+    with pytest.raises(ValueError):
+        build_row_plan(rowptr, 0, 2, -1, 16)
+    with pytest.raises(ValueError):
+        build_row_plan(rowptr, 0, 2, 4, 0)
+
+
+# ---------------------------------------------------------------------------------------------
+# partition
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+def test_balanced_ranges_tile_and_balance(world):
+    rng = np.random.default_rng(1)
+    deg = torch.from_numpy(np.minimum(rng.pareto(2.0, 5000) * 3 + 1, 400).astype(np.int64))
+    ranges = balanced_user_ranges(deg, world)
+    assert ranges[0][0] == 0 and ranges[-1][1] == 5000
+    assert all(ranges[k][1] == ranges[k + 1][0] for k in range(world - 1))
+    loads = [int(deg[a:b].sum()) for a, b in ranges]
+    assert sum(loads) == int(deg.sum())
+    assert max(loads) - min(loads) <= 2 * int(deg.max())          # within one (heaviest) user of even
+
+
+def test_balanced_ranges_degenerate_inputs():
+    assert balanced_user_ranges(torch.tensor([5]), 4) == [(0, 1), (1, 1), (1, 1), (1, 1)]
+    assert balanced_user_ranges(torch.zeros(0, dtype=torch.int64), 2) == [(0, 0), (0, 0)]
+    r = balanced_user_ranges(torch.tensor([0, 0, 10, 0]), 2)
+    assert r[0][0] == 0 and r[-1][1] == 4 and r[0][1] == r[1][0]
+    with pytest.raises(ValueError):
+        balanced_user_ranges(torch.tensor([1, 2]), 0)
+
+
+def test_check_bipartite():
+    good = torch.tensor([[0, 1, 3, 4], [3, 4, 0, 1]])
+    check_bipartite(good, 3, 2)
+    with pytest.raises(ValueError):
+        check_bipartite(torch.tensor([[0, 1], [1, 3]]), 3, 2)       # user-user edge
+    with pytest.raises(ValueError):
+        check_bipartite(torch.tensor([[0], [5]]), 3, 2)             # item id out of range
+
+
+# ---------------------------------------------------------------------------------------------
+# synthetic generator (SURVEY.md 8d rules)
+# ---------------------------------------------------------------------------------------------
+def test_generator_rules_config1():
+    g = synth.make_bipartite(**synth.CONFIG_SMALL, seed=0)
+    assert len(g.user) == 120_000 and g.nnz == 240_000
+    keys = g.user * g.n_items + g.item
+    assert len(np.unique(keys)) == len(keys)                                    # unique pairs
+    assert np.bincount(g.user, minlength=g.n_users).min() >= 1                  # every node covered
+    assert np.bincount(g.item, minlength=g.n_items).min() >= 1
+    assert set(np.unique(g.weight)).issubset(set(synth.WEIGHT_VALUES)) and g.weight.min() > 0
+    assert 0.10 < (g.weight == 1.0).mean() < 0.16
+    assert not np.all(np.diff(keys) > 0)                                        # shuffled
+    ei, ew = g.coo()
+    half = ei.size(1) // 2
+    assert ei.dtype == torch.int64 and ew.dtype == torch.float32 and ei.shape == (2, 240_000)
+    assert torch.equal(ei[0, :half], ei[1, half:]) and torch.equal(ei[1, :half], ei[0, half:])
+    assert ei[0, :half].max() < g.n_users <= ei[1, :half].min() and ei.max() == g.num_nodes - 1
+    g2 = synth.make_bipartite(**synth.CONFIG_SMALL, seed=0)
+    assert np.array_equal(g.user, g2.user) and np.array_equal(g.weight, g2.weight)          # seeded
+    assert not np.array_equal(g.user, synth.make_bipartite(**synth.CONFIG_SMALL, seed=1).user)
+    with pytest.raises(ValueError):
+        synth.make_bipartite(100, 10, 50)
+
+
+def test_algorithmic_bytes_match_baseline_md():
+    n, nnz = 1_693_929, 20_314_816
+    assert synth.algorithmic_bytes_per_layer(n, nnz, 64) == 1_036_585_896
+    assert synth.algorithmic_bytes_per_layer(n, nnz, 90) == 1_388_923_128
+    c = synth.CONFIG_COSMETICS
+    assert c["n_users"] + c["n_items"] == n and 2 * c["n_pairs"] == nnz
+
+
+def test_xavier_table_bound_and_seed():
+    w = synth.xavier_table(1000, 64, 3)
+    assert w.abs().max() <= (6 / 1064) ** 0.5 and torch.equal(w, synth.xavier_table(1000, 64, 3))
