@@ -29,8 +29,8 @@ constexpr int kWave = 64;
 constexpr int kBlock = 256;  // 4 wavefronts, one per SIMD of a CU
 
 typedef float f4 __attribute__((ext_vector_type(4)));
-// Row bases are only 8-byte aligned when D % 4 != 0 (D = 90 -> 360-byte rows): tell the
-// compiler, it still emits global_load_dwordx4 (gfx950 allows dword-aligned wide accesses).
+// Row slices are only dword-aligned in general (D = 90 -> 360-byte rows; the overlapping last lane):
+// tell the compiler, it still emits global_load_dwordx4 (gfx950 allows dword-aligned wide accesses).
 typedef f4 f4u __attribute__((aligned(4)));
 
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
@@ -188,6 +188,7 @@ struct SpmmArgs {
     int32_t row_begin, row_end, short_max;
 };
 
+// A lane's slice of a row: VEC consecutive floats starting at column c0.
 template <int VEC>
 struct Acc {
     float v[VEC];
@@ -197,145 +198,62 @@ struct Acc {
     }
 };
 
-// Load VEC floats of a row; the last lane of a D=90-style row holds fewer valid elements.
-template <int VEC, bool TAIL>
-__device__ __forceinline__ Acc<VEC> load_row(const float *p, int nvalid) {
+// Column of lane l's slice.  When D is not a multiple of 4 (D = 90) the LAST lane of the group takes
+// the final four columns, overlapping its neighbour by 4*LPR - D columns: every lane then issues the same
+// dwordx4 (no divergent narrow access for a tail), both lanes compute identical values for the shared
+// columns, and the overlapping stores write the same bits.
+template <int VEC>
+__device__ __forceinline__ int lane_column(int l, int dim) {
+    return VEC == 1 ? l : min(l * VEC, dim - VEC);
+}
+
+template <int VEC>
+__device__ __forceinline__ Acc<VEC> load_row(const float *p) {
     Acc<VEC> o;
     if constexpr (VEC == 4) {
-        if (!TAIL || nvalid == 4) {
-            f4 t = *reinterpret_cast<const f4u *>(p);
-            o.v[0] = t.x; o.v[1] = t.y; o.v[2] = t.z; o.v[3] = t.w;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) o.v[i] = i < nvalid ? p[i] : 0.0f;
-        }
+        f4 t = *reinterpret_cast<const f4u *>(p);
+        o.v[0] = t.x; o.v[1] = t.y; o.v[2] = t.z; o.v[3] = t.w;
     } else {
         o.v[0] = p[0];
     }
     return o;
 }
 
-// Streaming variants for data touched exactly once per hop (CSR entries, the epilogue row, the
-// output): non-temporal hints keep them from evicting the gathered rows -- the only data with
-// reuse -- out of the 4 MiB per-XCD L2.
-#ifndef LGC_NT
-#define LGC_NT 0  // measured on MI355X: nt hints cost 2.4 % on the full-size hop (842 vs 822 us)
-#endif
-template <typename T>
-__device__ __forceinline__ T stream_load(const T *p) {
-#if LGC_NT
-    return __builtin_nontemporal_load(p);
-#else
-    return *p;
-#endif
-}
-template <typename T>
-__device__ __forceinline__ void stream_store(T *p, T v) {
-#if LGC_NT
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
-__device__ __forceinline__ f4 stream_load_f4(const float *p) {
-#if LGC_NT
-    return __builtin_nontemporal_load(reinterpret_cast<const f4u *>(p));
-#else
-    return *reinterpret_cast<const f4u *>(p);
-#endif
-}
-__device__ __forceinline__ void stream_store_f4(float *p, f4 v) {
-#if LGC_NT
-    __builtin_nontemporal_store(v, reinterpret_cast<f4u *>(p));
-#else
-    *reinterpret_cast<f4u *>(p) = v;
-#endif
-}
-__device__ __forceinline__ lgc_entry load_entry(const lgc_entry *p) {
-    typedef int i2 __attribute__((ext_vector_type(2)));
-    i2 t = stream_load(reinterpret_cast<const i2 *>(p));
-    lgc_entry e;
-    e.col = t.x;
-    e.val = __int_as_float(t.y);
-    return e;
-}
-
-template <int VEC, bool TAIL>
-__device__ __forceinline__ Acc<VEC> load_row_stream(const float *p, int nvalid) {
-    Acc<VEC> o;
+template <int VEC>
+__device__ __forceinline__ void store_row(float *p, const Acc<VEC> &o) {
     if constexpr (VEC == 4) {
-        if (!TAIL || nvalid == 4) {
-            f4 t = stream_load_f4(p);
-            o.v[0] = t.x; o.v[1] = t.y; o.v[2] = t.z; o.v[3] = t.w;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) o.v[i] = i < nvalid ? stream_load(p + i) : 0.0f;
-        }
-    } else {
-        o.v[0] = stream_load(p);
-    }
-    return o;
-}
-
-template <int VEC, bool TAIL>
-__device__ __forceinline__ void store_row_stream(float *p, const Acc<VEC> &o, int nvalid) {
-    if constexpr (VEC == 4) {
-        if (!TAIL || nvalid == 4) {
-            f4 t = {o.v[0], o.v[1], o.v[2], o.v[3]};
-            stream_store_f4(p, t);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < nvalid) stream_store(p + i, o.v[i]);
-        }
-    } else {
-        stream_store(p, o.v[0]);
-    }
-}
-
-template <int VEC, bool TAIL>
-__device__ __forceinline__ void store_row(float *p, const Acc<VEC> &o, int nvalid) {
-    if constexpr (VEC == 4) {
-        if (!TAIL || nvalid == 4) {
-            f4 t = {o.v[0], o.v[1], o.v[2], o.v[3]};
-            *reinterpret_cast<f4u *>(p) = t;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < nvalid) p[i] = o.v[i];
-        }
+        f4 t = {o.v[0], o.v[1], o.v[2], o.v[3]};
+        *reinterpret_cast<f4u *>(p) = t;
     } else {
         p[0] = o.v[0];
     }
 }
 
 // acc = acc + val * x, product rounded before the add: the arithmetic of the reference's
-// "scale the gathered rows, then index_add_" (no FMA contraction).
+// "scale the gathered rows, then index_add_" (no FMA contraction; file built with -ffp-contract=off).
 template <int VEC>
 __device__ __forceinline__ void mul_add(Acc<VEC> &acc, float val, const Acc<VEC> &x) {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc.v[i] = __fadd_rn(acc.v[i], __fmul_rn(val, x.v[i]));
 }
 
-template <int VEC, bool TAIL>
-__device__ __forceinline__ void epilogue_store(const SpmmArgs &p, int64_t row, int c0, int nvalid, Acc<VEC> acc) {
+// y = a * acc + b * rv
+template <int VEC>
+__device__ __forceinline__ void finish_row(const SpmmArgs &p, int64_t row, int c0, Acc<VEC> acc, const Acc<VEC> &rv) {
     if (p.a != 1.0f) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc.v[i] = __fmul_rn(p.a, acc.v[i]);
     }
     if (p.r != nullptr) {
-        Acc<VEC> rv = load_row_stream<VEC, TAIL>(p.r + row * p.r_stride + c0, nvalid);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc.v[i] = __fadd_rn(acc.v[i], __fmul_rn(p.b, rv.v[i]));
     }
-    store_row_stream<VEC, TAIL>(p.y + row * p.y_stride + c0, acc, nvalid);
+    store_row<VEC>(p.y + row * p.y_stride + c0, acc);
 }
 
-#ifndef LGC_EARLY_R
-#define LGC_EARLY_R 1  // measured: issuing the epilogue row load ahead of the gathers = -3 % per hop
-#endif
-// Short rows: one lane group per row, entries in order, 4 gathers in flight per group.
-template <int VEC, bool TAIL>
+// Short rows: one lane group per row, entries in order, 4 gathers in flight per group; the epilogue
+// row is requested before the gathers and consumed after them.
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void k_spmm_rows(SpmmArgs p) {
     const int lane = threadIdx.x & (kWave - 1);
     const int rows_per_wave = kWave / p.lpr;
@@ -343,56 +261,41 @@ __global__ __launch_bounds__(kBlock) void k_spmm_rows(SpmmArgs p) {
     const int l = lane - g * p.lpr;
     const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x / kWave);
     const int64_t row = (int64_t)p.row_begin + wave * rows_per_wave + g;
-    const int c0 = l * VEC;
-    const int nvalid = min(VEC, p.dim - c0);
-    if (g >= rows_per_wave || row >= p.row_end || nvalid <= 0) return;
+    if (g >= rows_per_wave || row >= p.row_end) return;
+    const int c0 = lane_column<VEC>(l, p.dim);
 
     const int32_t s = p.rowptr[row], e = p.rowptr[row + 1];
     if (e - s > p.short_max) return;  // belongs to k_spmm_chunks
 
     const float *xb = p.x + c0;
     const lgc_entry *__restrict__ ent = p.entries;
-    Acc<VEC> acc;
+    Acc<VEC> acc, rv;
     acc.zero();
-#if LGC_EARLY_R
-    Acc<VEC> rv;
-    if (p.r != nullptr) rv = load_row<VEC, TAIL>(p.r + row * p.r_stride + c0, nvalid);
-#endif
+    rv.zero();
+    if (p.r != nullptr) rv = load_row<VEC>(p.r + row * p.r_stride + c0);
     int32_t k = s;
     for (; k + 4 <= e; k += 4) {
-        lgc_entry e0 = load_entry(ent + k), e1 = load_entry(ent + k + 1), e2 = load_entry(ent + k + 2), e3 = load_entry(ent + k + 3);
-        Acc<VEC> x0 = load_row<VEC, TAIL>(xb + (int64_t)e0.col * p.x_stride, nvalid);
-        Acc<VEC> x1 = load_row<VEC, TAIL>(xb + (int64_t)e1.col * p.x_stride, nvalid);
-        Acc<VEC> x2 = load_row<VEC, TAIL>(xb + (int64_t)e2.col * p.x_stride, nvalid);
-        Acc<VEC> x3 = load_row<VEC, TAIL>(xb + (int64_t)e3.col * p.x_stride, nvalid);
+        lgc_entry e0 = ent[k], e1 = ent[k + 1], e2 = ent[k + 2], e3 = ent[k + 3];
+        Acc<VEC> x0 = load_row<VEC>(xb + (int64_t)e0.col * p.x_stride);
+        Acc<VEC> x1 = load_row<VEC>(xb + (int64_t)e1.col * p.x_stride);
+        Acc<VEC> x2 = load_row<VEC>(xb + (int64_t)e2.col * p.x_stride);
+        Acc<VEC> x3 = load_row<VEC>(xb + (int64_t)e3.col * p.x_stride);
         mul_add<VEC>(acc, e0.val, x0);
         mul_add<VEC>(acc, e1.val, x1);
         mul_add<VEC>(acc, e2.val, x2);
         mul_add<VEC>(acc, e3.val, x3);
     }
     for (; k < e; ++k) {
-        lgc_entry e0 = load_entry(ent + k);
-        Acc<VEC> x0 = load_row<VEC, TAIL>(xb + (int64_t)e0.col * p.x_stride, nvalid);
+        lgc_entry e0 = ent[k];
+        Acc<VEC> x0 = load_row<VEC>(xb + (int64_t)e0.col * p.x_stride);
         mul_add<VEC>(acc, e0.val, x0);
     }
-#if LGC_EARLY_R
-    if (p.a != 1.0f) {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) acc.v[i] = __fmul_rn(p.a, acc.v[i]);
-    }
-    if (p.r != nullptr) {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) acc.v[i] = __fadd_rn(acc.v[i], __fmul_rn(p.b, rv.v[i]));
-    }
-    store_row<VEC, TAIL>(p.y + row * p.y_stride + c0, acc, nvalid);
-#else
-    epilogue_store<VEC, TAIL>(p, row, c0, nvalid, acc);
-#endif
+    finish_row<VEC>(p, row, c0, acc, rv);
 }
 
 // Long rows: one wavefront per chunk.  Lane group g takes entries begin+g, begin+g+G, ...;
 // the G group sums are then added in group order by lane group 0.
-template <int VEC, bool TAIL>
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void k_spmm_chunks(SpmmArgs p, const lgc_chunk *__restrict__ chunks,
                                                        int32_t n_chunks, float *__restrict__ partials) {
     const int lane = threadIdx.x & (kWave - 1);
@@ -402,9 +305,8 @@ __global__ __launch_bounds__(kBlock) void k_spmm_chunks(SpmmArgs p, const lgc_ch
     const int groups = kWave / p.lpr;
     const int g = lane / p.lpr;
     const int l = lane - g * p.lpr;
-    const int c0 = l * VEC;
-    const int nvalid = min(VEC, p.dim - c0);
-    const bool active = g < groups && nvalid > 0;
+    const int c0 = lane_column<VEC>(l, p.dim);
+    const bool active = g < groups;
 
     Acc<VEC> acc;
     acc.zero();
@@ -413,19 +315,19 @@ __global__ __launch_bounds__(kBlock) void k_spmm_chunks(SpmmArgs p, const lgc_ch
         const lgc_entry *__restrict__ ent = p.entries;
         int32_t k = ch.begin + g;
         for (; k + 3 * groups < ch.end; k += 4 * groups) {
-            lgc_entry e0 = load_entry(ent + k), e1 = load_entry(ent + k + groups), e2 = load_entry(ent + k + 2 * groups), e3 = load_entry(ent + k + 3 * groups);
-            Acc<VEC> x0 = load_row<VEC, TAIL>(xb + (int64_t)e0.col * p.x_stride, nvalid);
-            Acc<VEC> x1 = load_row<VEC, TAIL>(xb + (int64_t)e1.col * p.x_stride, nvalid);
-            Acc<VEC> x2 = load_row<VEC, TAIL>(xb + (int64_t)e2.col * p.x_stride, nvalid);
-            Acc<VEC> x3 = load_row<VEC, TAIL>(xb + (int64_t)e3.col * p.x_stride, nvalid);
+            lgc_entry e0 = ent[k], e1 = ent[k + groups], e2 = ent[k + 2 * groups], e3 = ent[k + 3 * groups];
+            Acc<VEC> x0 = load_row<VEC>(xb + (int64_t)e0.col * p.x_stride);
+            Acc<VEC> x1 = load_row<VEC>(xb + (int64_t)e1.col * p.x_stride);
+            Acc<VEC> x2 = load_row<VEC>(xb + (int64_t)e2.col * p.x_stride);
+            Acc<VEC> x3 = load_row<VEC>(xb + (int64_t)e3.col * p.x_stride);
             mul_add<VEC>(acc, e0.val, x0);
             mul_add<VEC>(acc, e1.val, x1);
             mul_add<VEC>(acc, e2.val, x2);
             mul_add<VEC>(acc, e3.val, x3);
         }
         for (; k < ch.end; k += groups) {
-            lgc_entry e0 = load_entry(ent + k);
-            Acc<VEC> x0 = load_row<VEC, TAIL>(xb + (int64_t)e0.col * p.x_stride, nvalid);
+            lgc_entry e0 = ent[k];
+            Acc<VEC> x0 = load_row<VEC>(xb + (int64_t)e0.col * p.x_stride);
             mul_add<VEC>(acc, e0.val, x0);
         }
     }
@@ -439,16 +341,19 @@ __global__ __launch_bounds__(kBlock) void k_spmm_chunks(SpmmArgs p, const lgc_ch
     }
     if (!active || g != 0) return;
     if (ch.slot >= 0) {
-        store_row<VEC, TAIL>(partials + (int64_t)ch.slot * p.dim + c0, acc, nvalid);
+        store_row<VEC>(partials + (int64_t)ch.slot * p.dim + c0, acc);
     } else {
-        epilogue_store<VEC, TAIL>(p, ch.row, c0, nvalid, acc);
+        Acc<VEC> rv;
+        rv.zero();
+        if (p.r != nullptr) rv = load_row<VEC>(p.r + (int64_t)ch.row * p.r_stride + c0);
+        finish_row<VEC>(p, ch.row, c0, acc, rv);
     }
 }
 
 // Rows cut into several chunks: one wavefront per row.  Lane group g adds slots g, g+G, g+2G, ...
 // (4 loads in flight per group), then the G group sums are added in group order -- a fixed
 // association, so the result does not depend on scheduling.
-template <int VEC, bool TAIL>
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void k_spmm_combine(SpmmArgs p, const lgc_multi_row *__restrict__ multi,
                                                         int32_t n_multi, const float *__restrict__ partials) {
     const int lane = threadIdx.x & (kWave - 1);
@@ -458,25 +363,24 @@ __global__ __launch_bounds__(kBlock) void k_spmm_combine(SpmmArgs p, const lgc_m
     const int groups = kWave / p.lpr;
     const int g = lane / p.lpr;
     const int l = lane - g * p.lpr;
-    const int c0 = l * VEC;
-    const int nvalid = min(VEC, p.dim - c0);
-    const bool active = g < groups && nvalid > 0;
+    const int c0 = lane_column<VEC>(l, p.dim);
+    const bool active = g < groups;
     Acc<VEC> acc;
     acc.zero();
     if (active) {
         const float *pb = partials + c0;
         int32_t s = mr.slot_begin + g;
         for (; s + 3 * groups < mr.slot_end; s += 4 * groups) {
-            Acc<VEC> t0 = load_row<VEC, TAIL>(pb + (int64_t)s * p.dim, nvalid);
-            Acc<VEC> t1 = load_row<VEC, TAIL>(pb + (int64_t)(s + groups) * p.dim, nvalid);
-            Acc<VEC> t2 = load_row<VEC, TAIL>(pb + (int64_t)(s + 2 * groups) * p.dim, nvalid);
-            Acc<VEC> t3 = load_row<VEC, TAIL>(pb + (int64_t)(s + 3 * groups) * p.dim, nvalid);
+            Acc<VEC> t0 = load_row<VEC>(pb + (int64_t)s * p.dim);
+            Acc<VEC> t1 = load_row<VEC>(pb + (int64_t)(s + groups) * p.dim);
+            Acc<VEC> t2 = load_row<VEC>(pb + (int64_t)(s + 2 * groups) * p.dim);
+            Acc<VEC> t3 = load_row<VEC>(pb + (int64_t)(s + 3 * groups) * p.dim);
 #pragma unroll
             for (int i = 0; i < VEC; ++i)
                 acc.v[i] = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(acc.v[i], t0.v[i]), t1.v[i]), t2.v[i]), t3.v[i]);
         }
         for (; s < mr.slot_end; s += groups) {
-            Acc<VEC> t0 = load_row<VEC, TAIL>(pb + (int64_t)s * p.dim, nvalid);
+            Acc<VEC> t0 = load_row<VEC>(pb + (int64_t)s * p.dim);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc.v[i] = __fadd_rn(acc.v[i], t0.v[i]);
         }
@@ -488,7 +392,12 @@ __global__ __launch_bounds__(kBlock) void k_spmm_combine(SpmmArgs p, const lgc_m
             if (g == 0) acc.v[i] = __fadd_rn(acc.v[i], other);
         }
     }
-    if (active && g == 0) epilogue_store<VEC, TAIL>(p, mr.row, c0, nvalid, acc);
+    if (active && g == 0) {
+        Acc<VEC> rv;
+        rv.zero();
+        if (p.r != nullptr) rv = load_row<VEC>(p.r + (int64_t)mr.row * p.r_stride + c0);
+        finish_row<VEC>(p, mr.row, c0, acc, rv);
+    }
 }
 
 __global__ void k_axpby(float *__restrict__ y, int64_t y_stride, const float *__restrict__ r, int64_t r_stride,
@@ -558,33 +467,21 @@ __global__ __launch_bounds__(kBlock) void k_pair_dot_bwd(const float *__restrict
 // dispatch helpers
 // ----------------------------------------------------------------------------------------
 struct DimCfg {
-    int vec;    // 4 or 1
-    bool tail;  // last lane of a row holds fewer than vec elements
+    int vec;  // 4 (any D >= 4, the last lane overlapping when D % 4 != 0) or 1 (D < 4)
     int lpr;
 };
 
 bool dim_cfg(int32_t dim, DimCfg *cfg) {
     if (dim < 1 || dim > 256) return false;
-    if (dim % 2 == 0) {
-        cfg->vec = 4;
-        cfg->tail = dim % 4 != 0;
-        cfg->lpr = (dim + 3) / 4;
-    } else {
-        if (dim > 64) return false;
-        cfg->vec = 1;
-        cfg->tail = false;
-        cfg->lpr = dim;
-    }
-    return cfg->lpr <= kWave;
+    cfg->vec = dim >= 4 ? 4 : 1;
+    cfg->lpr = dim >= 4 ? (dim + 3) / 4 : dim;
+    return true;
 }
 
 template <typename F>
 int dispatch_dim(const DimCfg &cfg, F &&f) {
-    if (cfg.vec == 4) {
-        if (cfg.tail) return f(std::integral_constant<int, 4>{}, std::true_type{});
-        return f(std::integral_constant<int, 4>{}, std::false_type{});
-    }
-    return f(std::integral_constant<int, 1>{}, std::false_type{});
+    if (cfg.vec == 4) return f(std::integral_constant<int, 4>{});
+    return f(std::integral_constant<int, 1>{});
 }
 
 bool aligned_to(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
@@ -678,33 +575,27 @@ int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin,
     if ((n_chunks > 0 && !chunks) || (n_multi > 0 && (!multi || !partials))) return LGC_E_INVAL;
     if (x_stride < dim || y_stride < dim || (r && r_stride < dim)) return LGC_E_INVAL;
     if (x == y) return LGC_E_INVAL;
-    if (cfg.vec == 4) {
-        const size_t al = cfg.tail ? 8 : 16;
-        const int64_t sm = cfg.tail ? 2 : 4;
-        if (!aligned_to(x, al) || !aligned_to(y, al) || (r && !aligned_to(r, al)) ||
-            (partials && !aligned_to(partials, al)))
-            return LGC_E_ALIGN;
-        if (x_stride % sm || y_stride % sm || (r && r_stride % sm)) return LGC_E_ALIGN;
-    }
+    // dwordx4 accesses need only dword alignment on gfx950; 16-byte aligned rows (D % 4 == 0, torch
+    // allocations) are the fast case, nothing else is rejected
+    if (!aligned_to(x, 4) || !aligned_to(y, 4) || (r && !aligned_to(r, 4))) return LGC_E_ALIGN;
     hipStream_t stream = as_stream(stream_);
     SpmmArgs p{rowptr, entries, x, y, r, x_stride, y_stride, r_stride, a, b, dim, cfg.lpr, row_begin, row_end, short_max};
     const int waves_per_block = kBlock / kWave;
     const int rows_per_wave = kWave / cfg.lpr;
-    return dispatch_dim(cfg, [&](auto vec, auto tail) -> int {
+    return dispatch_dim(cfg, [&](auto vec) -> int {
         constexpr int V = decltype(vec)::value;
-        constexpr bool T = decltype(tail)::value;
         const int64_t n_rows = (int64_t)row_end - row_begin;
         if (n_rows > 0) {
             int blocks = ceil_div(ceil_div(n_rows, rows_per_wave), waves_per_block);
-            hipLaunchKernelGGL((k_spmm_rows<V, T>), dim3(blocks), dim3(kBlock), 0, stream, p);
+            hipLaunchKernelGGL((k_spmm_rows<V>), dim3(blocks), dim3(kBlock), 0, stream, p);
         }
         if (n_chunks > 0) {
-            hipLaunchKernelGGL((k_spmm_chunks<V, T>), dim3(ceil_div(n_chunks, waves_per_block)), dim3(kBlock), 0,
+            hipLaunchKernelGGL((k_spmm_chunks<V>), dim3(ceil_div(n_chunks, waves_per_block)), dim3(kBlock), 0,
                                stream, p, chunks, n_chunks, partials);
         }
         if (n_multi > 0) {
             int blocks = ceil_div(n_multi, waves_per_block);
-            hipLaunchKernelGGL((k_spmm_combine<V, T>), dim3(blocks), dim3(kBlock), 0, stream, p, multi, n_multi,
+            hipLaunchKernelGGL((k_spmm_combine<V>), dim3(blocks), dim3(kBlock), 0, stream, p, multi, n_multi,
                                partials);
         }
         return (int)hipGetLastError();

@@ -16,6 +16,7 @@ saved activations:  d out / d x0 = sum_l alpha_l (A^T)^l.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -42,17 +43,32 @@ def _timed_apply(op: Operator, x: Tensor, out: Tensor, **kw) -> None:
     HOP_EVENT_LOG.append((start, end))
 
 
+def scratch_table(like: Tensor) -> Tensor:
+    """An internal [N, D] table.  Rows are padded to a multiple of 32 floats (128 B, one cache line) when D
+    is not one already (D = 90 -> stride 96), so that every gathered row covers whole lines: a 360-byte
+    row at stride 360 straddles 3.8 lines on average, at stride 384 exactly 3.  Only the API-facing
+    tables (embedding.weight in, the result out) keep the caller's dense layout."""
+    n, d = like.shape
+    if PAD_INTERNAL and d % 32 != 0:
+        stride = (d + 31) // 32 * 32
+        return torch.empty((n, stride), dtype=like.dtype, device=like.device)[:, :d]
+    return torch.empty_like(like)
+
+
+PAD_INTERNAL = os.environ.get("LGCN_PAD_INTERNAL", "1") == "1"
+
+
 def horner_hops(op: Operator, x0: Tensor, alphas: Sequence[float]) -> Tensor:
     """sum_l alphas[l] * op^l x0 with len(alphas)-1 launches of ``op.apply``."""
     k = len(alphas) - 1
     if k == 0:
         return x0 * alphas[0]
     x0 = x0.contiguous()
-    h = torch.empty_like(x0)
+    h = torch.empty_like(x0) if k == 1 else scratch_table(x0)
     # first hop reads x0 directly:  h_{K-1} = alpha_K * (A x0) + alpha_{K-1} * x0
     _timed_apply(op, x0, h, a=alphas[k], r=x0, b=alphas[k - 1])
     for layer in range(k - 2, -1, -1):
-        nxt = torch.empty_like(x0)
+        nxt = torch.empty_like(x0) if layer == 0 else scratch_table(x0)
         _timed_apply(op, h, nxt, a=1.0, r=x0, b=alphas[layer])
         h = nxt
     return h

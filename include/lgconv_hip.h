@@ -35,7 +35,7 @@ extern "C" {
 
 /* argument errors (negative return values) */
 #define LGC_E_INVAL      (-1)  /* null pointer, negative size, bad flag                    */
-#define LGC_E_DIM        (-2)  /* embedding width not supported (1..256, see lgc_dim_ok)   */
+#define LGC_E_DIM        (-2)  /* embedding width outside 1..256 (see lgc_dim_ok)           */
 #define LGC_E_WORKSPACE  (-3)  /* workspace smaller than lgc_build_workspace_bytes()        */
 #define LGC_E_RANGE      (-4)  /* node or edge count does not fit int32                     */
 #define LGC_E_ALIGN      (-5)  /* pointer / stride alignment requirement violated           */
@@ -119,8 +119,8 @@ int lgc_build_csr(const int64_t *edge_index, const float *edge_weight,
  *   partials[slot * dim ...]; `multi` rows then add their slots in order and apply the
  *   epilogue, which makes the result independent of scheduling.
  *
- *   x, y, r     fp32, row strides in floats; x/y/r rows must be 8-byte aligned, 16-byte when
- *               dim % 4 == 0;  y must not alias x
+ *   x, y, r     fp32, row strides in floats (>= dim); any dword-aligned rows are accepted, 16-byte
+ *               aligned rows (dim % 4 == 0) are the fast case;  y must not alias x
  *   partials    fp32 [n_slots, dim] or NULL when no chunk has slot >= 0
  * ------------------------------------------------------------------------------------- */
 int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries,

@@ -53,9 +53,9 @@ def test_error_strings_and_dim_support():
     assert lib.lgc_error_string(0) == b"ok"
     for code in (-1, -2, -3, -4, -5):
         assert lib.lgc_error_string(code) not in (b"ok", b"unknown error")
-    for dim in (1, 7, 16, 63, 64, 80, 90, 96, 128, 130, 256):
+    for dim in (1, 2, 3, 4, 5, 7, 16, 63, 64, 65, 80, 90, 96, 128, 129, 130, 255, 256):
         assert lib.lgc_dim_ok(dim) == 1
-    for dim in (0, -4, 65, 129, 257, 300):          # odd widths above 64 and anything above 256
+    for dim in (0, -4, 257, 300):                   # a row must fit one 64-lane wavefront of float4 slices
         assert lib.lgc_dim_ok(dim) == 0
     assert lib.lgc_build_workspace_bytes(1000, 5000) >= 4 * 5000 * 4
     assert lib.lgc_build_workspace_bytes(10, 2 ** 31) == 0          # does not fit int32
@@ -68,8 +68,8 @@ def test_argument_errors_are_reported_before_any_launch():
                         1.0, 0.0, 300, None) == -2                                      # LGC_E_DIM
     assert lib.lgc_spmm(one, one, 0, 4, 32, None, 0, None, 0, None, one, 64, one, 64, None, 0,
                         1.0, 0.0, 64, None) == -1                                       # y aliases x
-    assert lib.lgc_spmm(one, one, 0, 4, 32, None, 0, None, 0, None, ctypes.c_void_p(20), 64, ctypes.c_void_p(32), 64,
-                        None, 0, 1.0, 0.0, 64, None) == -5                              # misaligned x
+    assert lib.lgc_spmm(one, one, 0, 4, 32, None, 0, None, 0, None, ctypes.c_void_p(18), 64, ctypes.c_void_p(32), 64,
+                        None, 0, 1.0, 0.0, 64, None) == -5                              # x not dword-aligned
     assert lib.lgc_spmm(one, one, 0, 4, 32, None, 3, None, 0, None, one, 64, ctypes.c_void_p(32), 64, None, 0,
                         1.0, 0.0, 64, None) == -1                                       # chunks missing
     assert lib.lgc_build_csr(one, None, -1, 5, 0, 1, None, one, one, None, one, one, one, 1 << 20, one, None) == -1

@@ -92,7 +92,7 @@ def test_hub_degree_is_sequential(device):
     assert abs(deg[n_users].item() - w.double().sum().item()) > 0  # the fp32 chain really is inexact here
 
 
-@pytest.mark.parametrize("dim", [64, 80, 90, 16, 7, 128, 130])
+@pytest.mark.parametrize("dim", [64, 80, 90, 16, 7, 128, 130, 1, 2, 3, 4, 5, 6, 65, 129, 255, 256])
 def test_one_hop_vs_oracle(device, dim):
     g, ei, ew = small_graph(2)
     n = g.num_nodes

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[4] on one GPU: the mini-batch step of src/train_lightgcn.py:130-147
+(zero_grad -> labels -> forward -> bpr*size + reg -> backward -> Adam) on the cosmetics-scale graph.
+(u, i+, i-) are drawn uniformly with a seeded generator (the pandas sampler is out of scope)."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import gnn_ecommerce_amd as lg
+from gnn_ecommerce_amd import synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--dim", type=int, default=64); ap.add_argument("--layers", type=int, default=3)
+ap.add_argument("--steps", type=int, default=10); ap.add_argument("--batch", type=int, default=1024)
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+g = synth.make_bipartite(**synth.CONFIG_COSMETICS, seed=0)
+ei, ew = g.coo(dev)
+model = lg.LightGCN(g.num_nodes, args.dim, args.layers).to(dev)
+opt = torch.optim.Adam(model.parameters(), 0.005)
+gen = torch.Generator().manual_seed(0)
+def batch():
+    u = torch.randint(0, g.n_users, (args.batch,), generator=gen)
+    p = torch.randint(0, g.n_items, (args.batch,), generator=gen) + g.n_users
+    n = torch.randint(0, g.n_items, (args.batch,), generator=gen) + g.n_users
+    return u.to(dev), p.to(dev), n.to(dev)
+def step():
+    opt.zero_grad()
+    u, p, n = batch()
+    labels = torch.stack((torch.cat([u, u]), torch.cat([p, n])))
+    out = model(ei, labels, ew)
+    size = len(u)
+    bpr = model.recommendation_loss(out[:size], out[size:], 0) * size
+    w = model.embedding.weight
+    reg = 0.5 * (w[u].norm().pow(2) + w[p].norm().pow(2) + w[n].norm().pow(2)) / size * 1e-4
+    loss = bpr + reg
+    loss.backward()
+    opt.step()
+    return bpr.item(), reg.item(), loss.item()          # the three host syncs of train_lightgcn.py:149-151
+for _ in range(3): vals = step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(args.steps): vals = step()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / args.steps
+print(json.dumps({"metric": "training steps/s (fwd+bwd+Adam, B=%d)" % args.batch, "value": 1 / dt, "ms_per_step": dt * 1e3,
+                  "dim": args.dim, "layers": args.layers, "loss": vals[2]}))
