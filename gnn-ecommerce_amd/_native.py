@@ -17,7 +17,7 @@ import torch
 LIB_NAME = "liblgconv_hip.so"
 # LGCN_LIB_PATH selects another build of the SAME library (A/B kernel experiments); never a fallback.
 LIB_PATH = os.environ.get("LGCN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", LIB_NAME)
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # status bits (include/lgconv_hip.h)
 ST_INDEX_OOB = 1
@@ -30,10 +30,12 @@ SIGNATURES = {
     "lgc_build_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "lgc_build_csr": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p, c_void_p,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "lgc_build_slab": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "lgc_spmm": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32,
-                         c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float, c_float,
+                         c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float, c_float,
                          c_int32, c_void_p]),
     "lgc_axpby": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_float, c_float, c_int64, c_int32, c_void_p]),
+    "lgc_lincomb": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p]),
     "lgc_pair_dot": (c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                              c_void_p, c_void_p]),
     "lgc_pair_dot_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p,
@@ -93,6 +95,25 @@ def require_device(t: torch.Tensor, name: str) -> None:
         raise NativeLibraryError(
             f"{name} is on {t.device}: the LightGCN propagation path runs only on a ROCm device "
             "(MI355X); move the model and graph tensors to 'cuda'. No CPU fallback is provided.")
+
+
+MAX_TERMS = 8
+
+
+def lincomb(y: torch.Tensor, terms) -> torch.Tensor:
+    """y = sum_t coef_t * src_t over 2-D fp32 views of equal shape (``terms``: list of (coef, tensor))."""
+    lib = load()
+    n = len(terms)
+    if not 1 <= n <= MAX_TERMS:
+        raise ValueError(f"1..{MAX_TERMS} terms")
+    ptrs = (c_void_p * n)(*[t.data_ptr() for _, t in terms])
+    strides = (c_int64 * n)(*[t.stride(0) for _, t in terms])
+    coefs = (c_float * n)(*[float(c) for c, _ in terms])
+    with torch.cuda.device(y.device):
+        code = lib.lgc_lincomb(y.data_ptr(), y.stride(0), ptrs, strides, coefs, n, y.size(0), y.size(1),
+                               stream_of(y.device))
+    check(code, "lgc_lincomb")
+    return y
 
 
 def runtime_libraries() -> list:

@@ -186,6 +186,8 @@ struct SpmmArgs {
     float a, b;
     int32_t dim, lpr;  // lanes per row = ceil(dim / VEC)
     int32_t row_begin, row_end, short_max;
+    const lgc_entry *slab;
+    int32_t slab_width;
 };
 
 // A lane's slice of a row: VEC consecutive floats starting at column c0.
@@ -293,6 +295,94 @@ __global__ __launch_bounds__(kBlock) void k_spmm_rows(SpmmArgs p) {
     finish_row<VEC>(p, row, c0, acc, rv);
 }
 
+__global__ void k_build_slab(const int32_t *__restrict__ rowptr, const lgc_entry *__restrict__ entries,
+                             int64_t n_rows, int32_t width, lgc_entry *__restrict__ slab) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows * width) return;
+    const int64_t row = i / width;
+    const int32_t j = (int32_t)(i - row * width);
+    const int32_t s = rowptr[row], e = rowptr[row + 1];
+    lgc_entry v;
+    v.col = -1;
+    v.val = 0.0f;
+    if (s + j < e) v = entries[s + j];
+    slab[i] = v;
+}
+
+// Short rows through the slab: lane j < W of a row's group fetches entry j (one coalesced 8*W-byte
+// access per group, issued together with the row pointer and the epilogue row), the group then
+// broadcasts entry after entry with ds_bpermute and gathers.  Round trips per row: slab -> gathers ->
+// store, instead of rowptr -> entries -> gathers -> store.  Entry order is unchanged (bit-exact sums).
+template <int VEC, int W>
+__global__ __launch_bounds__(kBlock) void k_spmm_rows_slab(SpmmArgs p) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int rows_per_wave = kWave / p.lpr;
+    const int g = lane / p.lpr;
+    const int l = lane - g * p.lpr;
+    const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x / kWave);
+    const int64_t row = (int64_t)p.row_begin + wave * rows_per_wave + g;
+    const bool valid = g < rows_per_wave && row < p.row_end;
+    const int c0 = lane_column<VEC>(l, p.dim);
+    const int gbase = g * p.lpr;
+
+    lgc_entry mine;
+    mine.col = -1;
+    mine.val = 0.0f;
+    int32_t s = 0, e = 0;
+    Acc<VEC> acc, rv;
+    acc.zero();
+    rv.zero();
+    if (valid) {
+        if (l < W) mine = p.slab[row * W + l];
+        s = p.rowptr[row];
+        e = p.rowptr[row + 1];
+        if (p.r != nullptr) rv = load_row<VEC>(p.r + row * p.r_stride + c0);
+    }
+    const bool mine_row = valid && (e - s) <= p.short_max;   // longer rows belong to k_spmm_chunks
+    const int32_t n_head = mine_row ? min(e - s, W) : 0;
+    const float *xb = p.x + c0;
+#pragma unroll
+    for (int j0 = 0; j0 < W; j0 += 4) {
+        int32_t col[4];
+        float val[4];
+        Acc<VEC> xv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {   // every lane of the wave executes the shuffles
+            col[j] = __shfl(mine.col, gbase + j0 + j);
+            val[j] = __shfl(mine.val, gbase + j0 + j);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j0 + j < n_head) xv[j] = load_row<VEC>(xb + (int64_t)col[j] * p.x_stride);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j0 + j < n_head) mul_add<VEC>(acc, val[j], xv[j]);
+    }
+    if (!mine_row) return;
+    const lgc_entry *__restrict__ ent = p.entries;
+    int32_t k = s + W;
+    for (; k + 4 <= e; k += 4) {
+        lgc_entry e0 = ent[k], e1 = ent[k + 1], e2 = ent[k + 2], e3 = ent[k + 3];
+        Acc<VEC> x0 = load_row<VEC>(xb + (int64_t)e0.col * p.x_stride);
+        Acc<VEC> x1 = load_row<VEC>(xb + (int64_t)e1.col * p.x_stride);
+        Acc<VEC> x2 = load_row<VEC>(xb + (int64_t)e2.col * p.x_stride);
+        Acc<VEC> x3 = load_row<VEC>(xb + (int64_t)e3.col * p.x_stride);
+        mul_add<VEC>(acc, e0.val, x0);
+        mul_add<VEC>(acc, e1.val, x1);
+        mul_add<VEC>(acc, e2.val, x2);
+        mul_add<VEC>(acc, e3.val, x3);
+    }
+    for (; k < e; ++k) {
+        lgc_entry e0 = ent[k];
+        Acc<VEC> x0 = load_row<VEC>(xb + (int64_t)e0.col * p.x_stride);
+        mul_add<VEC>(acc, e0.val, x0);
+    }
+    finish_row<VEC>(p, row, c0, acc, rv);
+}
+
+#ifndef LGC_PIPE
+#define LGC_PIPE 1
+#endif
 // Long rows: one wavefront per chunk.  Lane group g takes entries begin+g, begin+g+G, ...;
 // the G group sums are then added in group order by lane group 0.
 template <int VEC>
@@ -314,6 +404,28 @@ __global__ __launch_bounds__(kBlock) void k_spmm_chunks(SpmmArgs p, const lgc_ch
         const float *xb = p.x + c0;
         const lgc_entry *__restrict__ ent = p.entries;
         int32_t k = ch.begin + g;
+#if LGC_PIPE
+        // software pipeline: the entries of step t+1 are requested before the gathers of step t are
+        // consumed, so a step costs one memory round trip (the gathers) instead of two
+        const int32_t step = 4 * groups;
+        lgc_entry n0, n1, n2, n3;
+        bool more = k + 3 * groups < ch.end;
+        if (more) { n0 = ent[k]; n1 = ent[k + groups]; n2 = ent[k + 2 * groups]; n3 = ent[k + 3 * groups]; }
+        while (more) {
+            const lgc_entry e0 = n0, e1 = n1, e2 = n2, e3 = n3;
+            Acc<VEC> x0 = load_row<VEC>(xb + (int64_t)e0.col * p.x_stride);
+            Acc<VEC> x1 = load_row<VEC>(xb + (int64_t)e1.col * p.x_stride);
+            Acc<VEC> x2 = load_row<VEC>(xb + (int64_t)e2.col * p.x_stride);
+            Acc<VEC> x3 = load_row<VEC>(xb + (int64_t)e3.col * p.x_stride);
+            k += step;
+            more = k + 3 * groups < ch.end;
+            if (more) { n0 = ent[k]; n1 = ent[k + groups]; n2 = ent[k + 2 * groups]; n3 = ent[k + 3 * groups]; }
+            mul_add<VEC>(acc, e0.val, x0);
+            mul_add<VEC>(acc, e1.val, x1);
+            mul_add<VEC>(acc, e2.val, x2);
+            mul_add<VEC>(acc, e3.val, x3);
+        }
+#else
         for (; k + 3 * groups < ch.end; k += 4 * groups) {
             lgc_entry e0 = ent[k], e1 = ent[k + groups], e2 = ent[k + 2 * groups], e3 = ent[k + 3 * groups];
             Acc<VEC> x0 = load_row<VEC>(xb + (int64_t)e0.col * p.x_stride);
@@ -325,6 +437,7 @@ __global__ __launch_bounds__(kBlock) void k_spmm_chunks(SpmmArgs p, const lgc_ch
             mul_add<VEC>(acc, e2.val, x2);
             mul_add<VEC>(acc, e3.val, x3);
         }
+#endif
         for (; k < ch.end; k += groups) {
             lgc_entry e0 = ent[k];
             Acc<VEC> x0 = load_row<VEC>(xb + (int64_t)e0.col * p.x_stride);
@@ -409,6 +522,25 @@ __global__ void k_axpby(float *__restrict__ y, int64_t y_stride, const float *__
         int32_t c = (int32_t)(i - row * dim);
         float v = __fmul_rn(a, y[row * y_stride + c]);
         if (r) v = __fadd_rn(v, __fmul_rn(b, r[row * r_stride + c]));
+        y[row * y_stride + c] = v;
+    }
+}
+
+struct LincombArgs {
+    const float *src[LGC_MAX_TERMS];
+    int64_t stride[LGC_MAX_TERMS];
+    float coef[LGC_MAX_TERMS];
+    int32_t n_terms;
+};
+
+__global__ void k_lincomb(float *__restrict__ y, int64_t y_stride, LincombArgs a, int64_t n_rows, int32_t dim) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = n_rows * dim;
+    for (; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / dim;
+        const int32_t c = (int32_t)(i - row * dim);
+        float v = __fmul_rn(a.coef[0], a.src[0][row * a.stride[0] + c]);
+        for (int t = 1; t < a.n_terms; ++t) v = __fadd_rn(v, __fmul_rn(a.coef[t], a.src[t][row * a.stride[t] + c]));
         y[row * y_stride + c] = v;
     }
 }
@@ -564,9 +696,18 @@ int lgc_build_csr(const int64_t *edge_index, const float *edge_weight, int64_t n
     return (int)hipGetLastError();
 }
 
+int lgc_build_slab(const int32_t *rowptr, const lgc_entry *entries, int64_t n_rows, int32_t width, lgc_entry *slab,
+                   void *stream_) {
+    if (!rowptr || !slab || n_rows < 0 || (width != 4 && width != 8 && width != 16)) return LGC_E_INVAL;
+    if (n_rows == 0) return 0;
+    hipLaunchKernelGGL(k_build_slab, dim3(ceil_div(n_rows * width, kBlock)), dim3(kBlock), 0, as_stream(stream_),
+                       rowptr, entries, n_rows, width, slab);
+    return (int)hipGetLastError();
+}
+
 int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin, int32_t row_end, int32_t short_max,
              const lgc_chunk *chunks, int32_t n_chunks, const lgc_multi_row *multi, int32_t n_multi, float *partials,
-             const float *x, int64_t x_stride, float *y, int64_t y_stride, const float *r, int64_t r_stride, float a,
+             const lgc_entry *slab, int32_t slab_width, const float *x, int64_t x_stride, float *y, int64_t y_stride, const float *r, int64_t r_stride, float a,
              float b, int32_t dim, void *stream_) {
     DimCfg cfg;
     if (!dim_cfg(dim, &cfg)) return LGC_E_DIM;
@@ -579,7 +720,10 @@ int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin,
     // allocations) are the fast case, nothing else is rejected
     if (!aligned_to(x, 4) || !aligned_to(y, 4) || (r && !aligned_to(r, 4))) return LGC_E_ALIGN;
     hipStream_t stream = as_stream(stream_);
-    SpmmArgs p{rowptr, entries, x, y, r, x_stride, y_stride, r_stride, a, b, dim, cfg.lpr, row_begin, row_end, short_max};
+    if (slab && slab_width != 4 && slab_width != 8 && slab_width != 16) return LGC_E_INVAL;
+    const bool use_slab = slab != nullptr && cfg.vec == 4 && cfg.lpr >= slab_width;
+    SpmmArgs p{rowptr, entries, x, y, r, x_stride, y_stride, r_stride, a, b, dim, cfg.lpr, row_begin, row_end,
+               short_max, use_slab ? slab : nullptr, use_slab ? slab_width : 0};
     const int waves_per_block = kBlock / kWave;
     const int rows_per_wave = kWave / cfg.lpr;
     return dispatch_dim(cfg, [&](auto vec) -> int {
@@ -587,7 +731,18 @@ int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin,
         const int64_t n_rows = (int64_t)row_end - row_begin;
         if (n_rows > 0) {
             int blocks = ceil_div(ceil_div(n_rows, rows_per_wave), waves_per_block);
-            hipLaunchKernelGGL((k_spmm_rows<V>), dim3(blocks), dim3(kBlock), 0, stream, p);
+            if constexpr (V == 4) {
+                if (p.slab_width == 4)
+                    hipLaunchKernelGGL((k_spmm_rows_slab<4, 4>), dim3(blocks), dim3(kBlock), 0, stream, p);
+                else if (p.slab_width == 8)
+                    hipLaunchKernelGGL((k_spmm_rows_slab<4, 8>), dim3(blocks), dim3(kBlock), 0, stream, p);
+                else if (p.slab_width == 16)
+                    hipLaunchKernelGGL((k_spmm_rows_slab<4, 16>), dim3(blocks), dim3(kBlock), 0, stream, p);
+                else
+                    hipLaunchKernelGGL((k_spmm_rows<V>), dim3(blocks), dim3(kBlock), 0, stream, p);
+            } else {
+                hipLaunchKernelGGL((k_spmm_rows<V>), dim3(blocks), dim3(kBlock), 0, stream, p);
+            }
         }
         if (n_chunks > 0) {
             hipLaunchKernelGGL((k_spmm_chunks<V>), dim3(ceil_div(n_chunks, waves_per_block)), dim3(kBlock), 0,
@@ -610,6 +765,25 @@ int lgc_axpby(float *y, int64_t y_stride, const float *r, int64_t r_stride, floa
     int blocks = (int)std::min<int64_t>(ceil_div(total, kBlock), 256 * 8);
     hipLaunchKernelGGL(k_axpby, dim3(blocks), dim3(kBlock), 0, as_stream(stream_), y, y_stride, r, r_stride, a, b,
                        n_rows, dim);
+    return (int)hipGetLastError();
+}
+
+int lgc_lincomb(float *y, int64_t y_stride, const float *const *src, const int64_t *src_stride, const float *coef,
+                int32_t n_terms, int64_t n_rows, int32_t dim, void *stream_) {
+    if (!y || !src || !src_stride || !coef || n_terms < 1 || n_terms > LGC_MAX_TERMS || n_rows < 0 || dim < 1 ||
+        y_stride < dim)
+        return LGC_E_INVAL;
+    LincombArgs a{};
+    a.n_terms = n_terms;
+    for (int t = 0; t < n_terms; ++t) {
+        if (!src[t] || src_stride[t] < dim) return LGC_E_INVAL;
+        a.src[t] = src[t];
+        a.stride[t] = src_stride[t];
+        a.coef[t] = coef[t];
+    }
+    if (n_rows == 0) return 0;
+    int blocks = (int)std::min<int64_t>(ceil_div(n_rows * dim, kBlock), 256 * 8);
+    hipLaunchKernelGGL(k_lincomb, dim3(blocks), dim3(kBlock), 0, as_stream(stream_), y, y_stride, a, n_rows, dim);
     return (int)hipGetLastError();
 }
 

@@ -28,6 +28,8 @@ from . import _native
 # are cut into chunks of about CHUNK_LEN entries, one wavefront each.
 SHORT_MAX = int(os.environ.get("LGCN_SHORT_MAX", "32"))
 CHUNK_LEN = int(os.environ.get("LGCN_CHUNK_LEN", "256"))
+# Width of the fixed slab of row heads the short-row kernel reads (0 = off): 4, 8 or 16 entries.
+SLAB_WIDTH = int(os.environ.get("LGCN_SLAB_WIDTH", "8"))
 
 
 @dataclass
@@ -94,6 +96,8 @@ class Operator:
     rowptr: Tensor
     entries: Tensor                      # int32 [E, 2]: column, fp32 bits of the value
     plan: RowPlan
+    slab: Optional[Tensor] = None        # int32 [n_rows * W, 2]: heads of every row, padded (lgc_build_slab)
+    slab_width: int = 0
     _partials: Dict[int, Tensor] = field(default_factory=dict)
 
     @property
@@ -136,6 +140,7 @@ class Operator:
                 _native.ptr(self.rowptr), _native.ptr(self.entries), p.row_begin, p.row_end, p.short_max,
                 _native.ptr(p.chunks) if p.n_chunks else None, p.n_chunks,
                 _native.ptr(p.multi) if p.n_multi else None, p.n_multi, _native.ptr(partials),
+                _native.ptr(self.slab), self.slab_width,
                 _native.ptr(x), x.stride(0), _native.ptr(out), out.stride(0),
                 _native.ptr(r), 0 if r is None else r.stride(0), float(a), float(b), dim,
                 _native.stream_of(x.device))
@@ -180,6 +185,8 @@ class PropGraph:
                             if keep_edge_values else None)
         self.forward_op = self._build(by_source=False)
         self._transpose_op: Optional[Operator] = None
+        self.split = self._find_bipartite_split()
+        self._halves = {}
 
     # -- construction ------------------------------------------------------------------
     def _build(self, by_source: bool, row_range: Optional[Tuple[int, int]] = None) -> Operator:
@@ -207,7 +214,40 @@ class PropGraph:
             raise IndexError(f"edge_index contains node ids outside [0, {n})")
         lo, hi = row_range if row_range is not None else (0, n)
         plan = build_row_plan(rowptr, lo, hi, self.short_max, self.chunk_len)
-        return Operator(n, rowptr, entries, plan)
+        slab, width = None, 0
+        if SLAB_WIDTH and e > 0:
+            width = SLAB_WIDTH
+            slab = torch.empty((n * width, 2), dtype=torch.int32, device=self.device)
+            with torch.cuda.device(self.device):
+                code = lib.lgc_build_slab(_native.ptr(rowptr), _native.ptr(entries), n, width, _native.ptr(slab),
+                                          _native.stream_of(self.device))
+            _native.check(code, "lgc_build_slab")
+        return Operator(n, rowptr, entries, plan, slab, width)
+
+    def _find_bipartite_split(self) -> Optional[int]:
+        """s such that every edge joins a node < s ("users") with a node >= s ("items") -- the layout of
+        src/utils_v2.py:146-165 -- or None.  Two reductions over the COO, one host sync per graph."""
+        if self.num_edges == 0:
+            return None
+        lo = torch.minimum(self._edge_index[0], self._edge_index[1]).max()
+        hi = torch.maximum(self._edge_index[0], self._edge_index[1]).min()
+        lo, hi = int(lo.item()), int(hi.item())
+        return lo + 1 if lo < hi else None
+
+    def halves(self, transpose: bool = False) -> Tuple[Operator, Operator]:
+        """(user-row operator, item-row operator): the same CSR with work plans limited to rows [0, split)
+        and [split, N).  Only for bipartite graphs."""
+        if self.split is None:
+            raise ValueError("graph is not bipartite")
+        got = self._halves.get(transpose)
+        if got is None:
+            op = self.transpose_op if transpose else self.forward_op
+            got = tuple(Operator(op.n_rows, op.rowptr, op.entries,
+                                 build_row_plan(op.rowptr, lo, hi, self.short_max, self.chunk_len),
+                                 op.slab, op.slab_width)
+                        for lo, hi in ((0, self.split), (self.split, self.num_nodes)))
+            self._halves[transpose] = got
+        return got
 
     @property
     def transpose_op(self) -> Operator:

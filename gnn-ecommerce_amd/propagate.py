@@ -74,16 +74,76 @@ def horner_hops(op: Operator, x0: Tensor, alphas: Sequence[float]) -> Tensor:
     return h
 
 
+USE_BIPARTITE = os.environ.get("LGCN_BIPARTITE", "1") == "1"
+
+
+class _HopSpan:
+    """Events around one layer's launches (both halves), appended to HOP_EVENT_LOG when bench.py asks."""
+
+    def __enter__(self):
+        self.log = HOP_EVENT_LOG
+        if self.log is not None:
+            self.start, self.end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.start.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.log is not None:
+            self.end.record()
+            self.log.append((self.start, self.end))
+
+
+def bipartite_sum(user_op: Operator, item_op: Operator, split: int, x0: Tensor, alphas: Sequence[float]) -> Tensor:
+    """sum_l alpha_l A^l x0 for A = [[0, R], [R^T, 0]] (users first), K = len(alphas) - 1 layers.
+
+    With x_l = A^l x0:  x_l[items] = R^T x_{l-1}[users]  (item step, gathers user rows) and
+    x_l[users] = R x_{l-1}[items]  (user step, gathers item rows).  Because the user side is linear in the
+    item tables,
+        out[users] = alpha_0 x0[users] + R ( sum_{l=1..K} alpha_l x_{l-1}[items] ),
+    so the K-th user table is never materialised, only ONE user step (the last) reads an epilogue row,
+    and the weighted sums over layers are taken on the small item tables only (``lgc_lincomb``, in the
+    reference's own order: out = out + x * alpha).  Same K item steps + K user steps as K plain hops.
+    """
+    k = len(alphas) - 1
+    if k == 0:
+        return x0 * alphas[0]
+    x0 = x0.contiguous()
+    n = x0.size(0)
+    tables = [x0]                                     # x_0 .. x_K (x_K: item rows only)
+    for layer in range(1, k + 1):
+        with _HopSpan():
+            nxt = scratch_table(x0)
+            item_op.apply(tables[-1], nxt)                                      # x_l[items]
+            if layer < k:
+                user_op.apply(tables[-1], nxt)                                  # x_l[users]
+                tables.append(nxt)
+            else:
+                tables.append(nxt)
+                out = torch.empty_like(x0)
+                mix = scratch_table(x0)                                         # item rows: sum_l alpha_l x_{l-1}
+                _native.lincomb(mix[split:], [(alphas[l], tables[l - 1][split:]) for l in range(1, k + 1)])
+                _native.lincomb(out[split:], [(alphas[l], tables[l][split:]) for l in range(0, k + 1)])
+                user_op.apply(mix, out, a=1.0, r=x0, b=alphas[0])                # out[users]
+    return out
+
+
+def _layer_sum(graph: PropGraph, x: Tensor, alphas: tuple, transpose: bool) -> Tensor:
+    if USE_BIPARTITE and graph.split is not None and len(alphas) - 1 <= _native.MAX_TERMS - 1:
+        user_op, item_op = graph.halves(transpose)
+        return bipartite_sum(user_op, item_op, graph.split, x, alphas)
+    return horner_hops(graph.transpose_op if transpose else graph.forward_op, x, alphas)
+
+
 class _PropagateSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0: Tensor, graph: PropGraph, alphas: tuple) -> Tensor:
         ctx.graph, ctx.alphas = graph, alphas
-        return horner_hops(graph.forward_op, x0.detach(), alphas)
+        return _layer_sum(graph, x0.detach(), alphas, transpose=False)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_out: Tensor):
-        return horner_hops(ctx.graph.transpose_op, grad_out.contiguous(), ctx.alphas), None, None
+        return _layer_sum(ctx.graph, grad_out.contiguous(), ctx.alphas, transpose=True), None, None
 
 
 class _Hop(torch.autograd.Function):

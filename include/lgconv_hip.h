@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LGC_ABI_VERSION 1
+#define LGC_ABI_VERSION 2
 
 /* argument errors (negative return values) */
 #define LGC_E_INVAL      (-1)  /* null pointer, negative size, bad flag                    */
@@ -106,6 +106,13 @@ int lgc_build_csr(const int64_t *edge_index, const float *edge_weight,
                   void *workspace, size_t workspace_bytes,
                   int32_t *status, void *stream);
 
+/* Fixed-width slab of the CSR's row heads: slab[row * width + j] = entries[rowptr[row] + j] for
+ * j < min(degree, width), {col = -1, val = 0} beyond.  With it lgc_spmm fetches a short row's entries in
+ * the same memory round trip as its row pointer (the address depends on the row id only), which is what
+ * bounds the short-row kernel.  width: 4, 8 or 16.  slab: lgc_entry [n_rows * width]. */
+int lgc_build_slab(const int32_t *rowptr, const lgc_entry *entries, int64_t n_rows, int32_t width,
+                   lgc_entry *slab, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * One propagation hop:  y[row] = a * sum_k entries[k].val * x[entries[k].col] + b * r[row]
  * for row in [row_begin, row_end) and for the rows named by `chunks`.
@@ -122,11 +129,14 @@ int lgc_build_csr(const int64_t *edge_index, const float *edge_weight,
  *   x, y, r     fp32, row strides in floats (>= dim); any dword-aligned rows are accepted, 16-byte
  *               aligned rows (dim % 4 == 0) are the fast case;  y must not alias x
  *   partials    fp32 [n_slots, dim] or NULL when no chunk has slot >= 0
+ *   slab, slab_width  from lgc_build_slab, or NULL/0: then short rows read their entries through rowptr.
+ *               Used only when a row's lane group has at least slab_width lanes (dim >= 4 * slab_width).
  * ------------------------------------------------------------------------------------- */
 int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries,
              int32_t row_begin, int32_t row_end, int32_t short_max,
              const lgc_chunk *chunks, int32_t n_chunks,
              const lgc_multi_row *multi, int32_t n_multi, float *partials,
+             const lgc_entry *slab, int32_t slab_width,
              const float *x, int64_t x_stride,
              float *y, int64_t y_stride,
              const float *r, int64_t r_stride,
@@ -135,6 +145,14 @@ int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries,
 /* y[i, :dim] = a * y[i, :dim] + b * r[i, :dim]  for i < n_rows (epilogue after an exchange). */
 int lgc_axpby(float *y, int64_t y_stride, const float *r, int64_t r_stride,
               float a, float b, int64_t n_rows, int32_t dim, void *stream);
+
+/* y[i, :dim] = sum_t coef[t] * src[t][i, :dim]  for i < n_rows, terms added in index order, each product
+ * rounded before its add -- the order of the reference's running layer sum `out = out + x * alpha`
+ * (src/lightgcn.py:93,97).  `src`, `src_stride`, `coef` are HOST arrays of n_terms (1..LGC_MAX_TERMS) entries;
+ * src[t] are device pointers.  y may alias one of the sources (element-wise). */
+#define LGC_MAX_TERMS 8
+int lgc_lincomb(float *y, int64_t y_stride, const float *const *src, const int64_t *src_stride,
+                const float *coef, int32_t n_terms, int64_t n_rows, int32_t dim, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Pair scoring: scores[m] = <emb[idx0[m]], emb[idx1[m]]>.
