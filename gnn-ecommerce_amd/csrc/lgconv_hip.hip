@@ -188,6 +188,7 @@ struct SpmmArgs {
     int32_t row_begin, row_end, short_max;
     const lgc_entry *slab;
     int32_t slab_width;
+    int32_t wt_store;  // 1: output rows leave with write-through (sc1) stores, see store_out
 };
 
 // A lane's slice of a row: VEC consecutive floats starting at column c0.
@@ -231,6 +232,28 @@ __device__ __forceinline__ void store_row(float *p, const Acc<VEC> &o) {
     }
 }
 
+// Output rows are written once and not read again in this launch.  A plain store keeps its line in the
+// XCD's 4 MiB L2, where 0.42 GB of output per layer evicts the gathered rows (the only data with reuse);
+// an sc1 (write-through) store drops the line from L2 instead (MI355X_MICROARCH.md, table of store
+// flavours).  Needs a buffer descriptor: 32-bit byte offsets, so only for tables below 4 GiB (wt_store).
+#ifndef LGC_WT
+#define LGC_WT 1
+#endif
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+template <int VEC>
+__device__ __forceinline__ void store_out(const SpmmArgs &p, int64_t row, int c0, const Acc<VEC> &o) {
+    if constexpr (VEC == 4 && LGC_WT) {
+        if (p.wt_store) {
+            auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.y, 0, 0xFFFFFFFFu, 0x00020000);
+            f4 t = {o.v[0], o.v[1], o.v[2], o.v[3]};
+            const unsigned off = (unsigned)((row * p.y_stride + c0) * 4);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, t), rsrc, off, 0, /*sc1*/ 16);
+            return;
+        }
+    }
+    store_row<VEC>(p.y + row * p.y_stride + c0, o);
+}
+
 // acc = acc + val * x, product rounded before the add: the arithmetic of the reference's
 // "scale the gathered rows, then index_add_" (no FMA contraction; file built with -ffp-contract=off).
 template <int VEC>
@@ -250,7 +273,7 @@ __device__ __forceinline__ void finish_row(const SpmmArgs &p, int64_t row, int c
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc.v[i] = __fadd_rn(acc.v[i], __fmul_rn(p.b, rv.v[i]));
     }
-    store_row<VEC>(p.y + row * p.y_stride + c0, acc);
+    store_out<VEC>(p, row, c0, acc);
 }
 
 // Short rows: one lane group per row, entries in order, 4 gathers in flight per group; the epilogue
@@ -707,11 +730,12 @@ int lgc_build_slab(const int32_t *rowptr, const lgc_entry *entries, int64_t n_ro
 
 int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin, int32_t row_end, int32_t short_max,
              const lgc_chunk *chunks, int32_t n_chunks, const lgc_multi_row *multi, int32_t n_multi, float *partials,
-             const lgc_entry *slab, int32_t slab_width, const float *x, int64_t x_stride, float *y, int64_t y_stride, const float *r, int64_t r_stride, float a,
+             const lgc_entry *slab, int32_t slab_width, int64_t table_rows, const float *x, int64_t x_stride, float *y, int64_t y_stride, const float *r, int64_t r_stride, float a,
              float b, int32_t dim, void *stream_) {
     DimCfg cfg;
     if (!dim_cfg(dim, &cfg)) return LGC_E_DIM;
-    if (!rowptr || !x || !y || row_begin < 0 || row_end < row_begin || n_chunks < 0 || n_multi < 0 || short_max < 0)
+    if (!rowptr || !x || !y || row_begin < 0 || row_end < row_begin || n_chunks < 0 || n_multi < 0 || short_max < 0 ||
+        table_rows < row_end)
         return LGC_E_INVAL;
     if ((n_chunks > 0 && !chunks) || (n_multi > 0 && (!multi || !partials))) return LGC_E_INVAL;
     if (x_stride < dim || y_stride < dim || (r && r_stride < dim)) return LGC_E_INVAL;
@@ -723,7 +747,9 @@ int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin,
     if (slab && slab_width != 4 && slab_width != 8 && slab_width != 16) return LGC_E_INVAL;
     const bool use_slab = slab != nullptr && cfg.vec == 4 && cfg.lpr >= slab_width;
     SpmmArgs p{rowptr, entries, x, y, r, x_stride, y_stride, r_stride, a, b, dim, cfg.lpr, row_begin, row_end,
-               short_max, use_slab ? slab : nullptr, use_slab ? slab_width : 0};
+               short_max, use_slab ? slab : nullptr, use_slab ? slab_width : 0, 0};
+    // write-through output stores address y with 32-bit byte offsets
+    p.wt_store = (table_rows * y_stride * 4 < (int64_t(1) << 32)) ? 1 : 0;
     const int waves_per_block = kBlock / kWave;
     const int rows_per_wave = kWave / cfg.lpr;
     return dispatch_dim(cfg, [&](auto vec) -> int {

@@ -140,7 +140,7 @@ class Operator:
                 _native.ptr(self.rowptr), _native.ptr(self.entries), p.row_begin, p.row_end, p.short_max,
                 _native.ptr(p.chunks) if p.n_chunks else None, p.n_chunks,
                 _native.ptr(p.multi) if p.n_multi else None, p.n_multi, _native.ptr(partials),
-                _native.ptr(self.slab), self.slab_width,
+                _native.ptr(self.slab), self.slab_width, min(x.size(0), out.size(0)),
                 _native.ptr(x), x.stride(0), _native.ptr(out), out.stride(0),
                 _native.ptr(r), 0 if r is None else r.stride(0), float(a), float(b), dim,
                 _native.stream_of(x.device))

@@ -126,6 +126,7 @@ int lgc_build_slab(const int32_t *rowptr, const lgc_entry *entries, int64_t n_ro
  *   partials[slot * dim ...]; `multi` rows then add their slots in order and apply the
  *   epilogue, which makes the result independent of scheduling.
  *
+ *   table_rows  number of rows of the x / y / r tables (every row and column index is below it)
  *   x, y, r     fp32, row strides in floats (>= dim); any dword-aligned rows are accepted, 16-byte
  *               aligned rows (dim % 4 == 0) are the fast case;  y must not alias x
  *   partials    fp32 [n_slots, dim] or NULL when no chunk has slot >= 0
@@ -137,6 +138,7 @@ int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries,
              const lgc_chunk *chunks, int32_t n_chunks,
              const lgc_multi_row *multi, int32_t n_multi, float *partials,
              const lgc_entry *slab, int32_t slab_width,
+             int64_t table_rows,
              const float *x, int64_t x_stride,
              float *y, int64_t y_stride,
              const float *r, int64_t r_stride,

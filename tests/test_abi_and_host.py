@@ -64,13 +64,13 @@ def test_error_strings_and_dim_support():
 def test_argument_errors_are_reported_before_any_launch():
     lib = _native.load()
     one = ctypes.c_void_p(16)            # never dereferenced: every call below must fail validation first
-    assert lib.lgc_spmm(one, one, 0, 4, 32, None, 0, None, 0, None, None, 0, one, 64, ctypes.c_void_p(32), 64, None, 0,
+    assert lib.lgc_spmm(one, one, 0, 4, 32, None, 0, None, 0, None, None, 0, 8, one, 64, ctypes.c_void_p(32), 64, None, 0,
                         1.0, 0.0, 300, None) == -2                                      # LGC_E_DIM
-    assert lib.lgc_spmm(one, one, 0, 4, 32, None, 0, None, 0, None, None, 0, one, 64, one, 64, None, 0,
+    assert lib.lgc_spmm(one, one, 0, 4, 32, None, 0, None, 0, None, None, 0, 8, one, 64, one, 64, None, 0,
                         1.0, 0.0, 64, None) == -1                                       # y aliases x
-    assert lib.lgc_spmm(one, one, 0, 4, 32, None, 0, None, 0, None, None, 0, ctypes.c_void_p(18), 64, ctypes.c_void_p(32), 64,
+    assert lib.lgc_spmm(one, one, 0, 4, 32, None, 0, None, 0, None, None, 0, 8, ctypes.c_void_p(18), 64, ctypes.c_void_p(32), 64,
                         None, 0, 1.0, 0.0, 64, None) == -5                              # x not dword-aligned
-    assert lib.lgc_spmm(one, one, 0, 4, 32, None, 3, None, 0, None, None, 0, one, 64, ctypes.c_void_p(32), 64, None, 0,
+    assert lib.lgc_spmm(one, one, 0, 4, 32, None, 3, None, 0, None, None, 0, 8, one, 64, ctypes.c_void_p(32), 64, None, 0,
                         1.0, 0.0, 64, None) == -1                                       # chunks missing
     assert lib.lgc_build_csr(one, None, -1, 5, 0, 1, None, one, one, None, one, one, one, 1 << 20, one, None) == -1
     assert lib.lgc_build_csr(one, None, 10, 5, 1, 1, None, one, one, None, one, one, one, 1 << 20, one, None) == -1
