@@ -17,7 +17,7 @@ import torch
 LIB_NAME = "liblgconv_hip.so"
 # LGCN_LIB_PATH selects another build of the SAME library (A/B kernel experiments); never a fallback.
 LIB_PATH = os.environ.get("LGCN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", LIB_NAME)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # status bits (include/lgconv_hip.h)
 ST_INDEX_OOB = 1
@@ -34,6 +34,9 @@ SIGNATURES = {
     "lgc_spmm": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32,
                          c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float, c_float,
                          c_int32, c_void_p]),
+    "lgc_spmm_sweep": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int64,
+                               c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float, c_float, c_int32,
+                               c_void_p]),
     "lgc_axpby": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_float, c_float, c_int64, c_int32, c_void_p]),
     "lgc_lincomb": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p]),
     "lgc_pair_dot": (c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
