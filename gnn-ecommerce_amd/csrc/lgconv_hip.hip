@@ -27,7 +27,6 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int kBlock = 256;  // 4 wavefronts, one per SIMD of a CU
-constexpr int kNumCUs = 256;  // MI355X
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 // Row slices are only dword-aligned in general (D = 90 -> 360-byte rows; the overlapping last lane):
@@ -537,114 +536,6 @@ __global__ __launch_bounds__(kBlock) void k_spmm_combine(SpmmArgs p, const lgc_m
     }
 }
 
-// ----------------------------------------------------------------------------------------
-// Sweep: long rows with LDS-resident accumulators (see lgc_spmm_sweep in the header)
-// ----------------------------------------------------------------------------------------
-constexpr int kSweepThreads = 1024;
-constexpr int kSweepWaves = kSweepThreads / kWave;
-constexpr int kSweepLdsFloats = LGC_SWEEP_LDS_BYTES / 4;   // two panels fit one CU's 160 KiB
-
-struct SweepArgs {
-    const lgc_entry *pedges;
-    const int32_t *wave_ptr;
-    const int32_t *acc_slot;
-    const float *x;
-    float *partials;
-    int64_t x_stride;
-    int32_t n_bands, panels_per_band, acc_per_unit, dim, lpr;
-    int32_t panel_offset;   // first panel (inside every band) of this pass
-};
-
-// One 1024-thread workgroup per panel, and inside it every LANE GROUP is a unit of its own: it owns
-// acc_per_unit accumulator rows of the LDS image and the column-ordered list of the entries that feed
-// them, so a row is only ever touched by one lane group -- plain ds_read_b128 / add / ds_write_b128, no
-// atomics (fp32 LDS atomics measured at ~4 cycles per lane here), and a fixed summation order.
-// A wavefront fetches 64 entries per coalesced load: lanes [g*per, (g+1)*per) hold the next `per`
-// entries of lane group g (per = 64 / groups); at step s group g picks up its entry s with two
-// ds_bpermute, gathers its float4 slice of the source row (4 row gathers in flight per group) and
-// updates its accumulator.  The LDS row of an accumulator stores the lanes' slices back to back
-// (lane l at 4l), duplicates of an overlapping last lane included.
-__global__ __launch_bounds__(kSweepThreads) void k_spmm_sweep(SweepArgs p) {
-    __shared__ __attribute__((aligned(16))) float lds[kSweepLdsFloats];
-    const int band = blockIdx.x % p.n_bands;
-    const int panel = band * p.panels_per_band + p.panel_offset + blockIdx.x / p.n_bands;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x / kWave;
-    const int32_t eb = p.wave_ptr[panel * kSweepWaves + wave], ee = p.wave_ptr[panel * kSweepWaves + wave + 1];
-    if (eb == ee) return;  // wave-uniform; nothing below synchronises the workgroup
-
-    const int groups = kWave / p.lpr;
-    const int per = kWave / groups;
-    const int g = lane / p.lpr;
-    const int l = lane - g * p.lpr;
-    const bool active = g < groups;
-    const int c0 = min(l * 4, p.dim - 4);
-    const int pitch = p.lpr * 4;
-    const int unit = wave * groups + g;
-    float *mine_rows = lds + (int64_t)unit * p.acc_per_unit * pitch + l * 4;
-    if (active) {
-        const f4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int j = 0; j < p.acc_per_unit; ++j) *reinterpret_cast<f4 *>(mine_rows + j * pitch) = z;
-    }
-    const float *xb = p.x + c0;
-    // Software pipeline over steps of 4 entries per lane group: the gathers of step t+1 are in flight
-    // while step t's rows are added into LDS (a dependent read-add-write chain per entry).
-    const int steps_per_batch = (per + 3) / 4;
-    const int64_t n_steps = (int64_t)((ee - eb) / kWave) * steps_per_batch;
-    lgc_entry mine = p.pedges[eb + lane];
-    int col[4], ncol[4];
-    float val[4], nval[4];
-    Acc<4> xv[4], nxv[4];
-    auto fetch = [&](int64_t t, const lgc_entry &m, int (&c)[4], float (&w)[4], Acc<4> (&xr)[4]) {
-        const int s0 = (int)(t % steps_per_batch) * 4;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {                  // every lane executes the shuffles
-            const int src = min(g * per + s0 + u, kWave - 1);
-            c[u] = __shfl(m.col, src);
-            w[u] = (s0 + u < per) ? __shfl(m.val, src) : 0.0f;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (active) xr[u] = load_row<4>(xb + (int64_t)(c[u] & ((1 << LGC_SWEEP_SHIFT) - 1)) * p.x_stride);
-    };
-    fetch(0, mine, col, val, xv);
-    for (int64_t t = 0; t < n_steps; ++t) {
-        const bool more = t + 1 < n_steps;
-        if (more) {
-            if ((t + 1) % steps_per_batch == 0) mine = p.pedges[eb + ((t + 1) / steps_per_batch) * kWave + lane];
-            fetch(t + 1, mine, ncol, nval, nxv);
-        }
-        if (active) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                f4 *row = reinterpret_cast<f4 *>(mine_rows + (((unsigned)col[u]) >> LGC_SWEEP_SHIFT) * pitch);
-                f4 a4 = *row;
-                a4.x = __fadd_rn(a4.x, __fmul_rn(val[u], xv[u].v[0]));
-                a4.y = __fadd_rn(a4.y, __fmul_rn(val[u], xv[u].v[1]));
-                a4.z = __fadd_rn(a4.z, __fmul_rn(val[u], xv[u].v[2]));
-                a4.w = __fadd_rn(a4.w, __fmul_rn(val[u], xv[u].v[3]));
-                *row = a4;
-            }
-        }
-        if (more) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                col[u] = ncol[u];
-                val[u] = nval[u];
-                xv[u] = nxv[u];
-            }
-        }
-    }
-    if (!active) return;
-    const int32_t *slots = p.acc_slot + ((int64_t)panel * kSweepWaves * groups + unit) * p.acc_per_unit;
-    for (int j = 0; j < p.acc_per_unit; ++j) {
-        const int32_t slot = slots[j];
-        if (slot < 0) continue;
-        const f4 t = *reinterpret_cast<const f4 *>(mine_rows + j * pitch);
-        *reinterpret_cast<f4u *>(p.partials + (int64_t)slot * p.dim + c0) = t;
-    }
-}
-
 __global__ void k_axpby(float *__restrict__ y, int64_t y_stride, const float *__restrict__ r, int64_t r_stride,
                         float a, float b, int64_t n_rows, int32_t dim) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -890,50 +781,6 @@ int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin,
         }
         return (int)hipGetLastError();
     });
-}
-
-int lgc_spmm_sweep(const lgc_entry *pedges, const int32_t *wave_ptr, const int32_t *acc_slot, int32_t n_bands,
-                   int32_t panels_per_band, int32_t acc_per_unit, const lgc_multi_row *multi, int32_t n_multi, float *partials,
-                   int64_t table_rows, const float *x, int64_t x_stride, float *y, int64_t y_stride, const float *r,
-                   int64_t r_stride, float a, float b, int32_t dim, void *stream_) {
-    DimCfg cfg;
-    if (!dim_cfg(dim, &cfg)) return LGC_E_DIM;
-    if (!pedges || !wave_ptr || !acc_slot || !x || !y || !partials || n_bands < 1 || panels_per_band < 0 ||
-        n_multi < 0 || (n_multi > 0 && !multi) || table_rows < 0)
-        return LGC_E_INVAL;
-    if (x_stride < dim || y_stride < dim || (r && r_stride < dim) || x == y) return LGC_E_INVAL;
-    if (table_rows >= (int64_t(1) << LGC_SWEEP_SHIFT)) return LGC_E_RANGE;
-    hipStream_t stream = as_stream(stream_);
-    if (panels_per_band > 0) {
-        const int units = kSweepWaves * (kWave / cfg.lpr);
-        if (cfg.vec != 4 || acc_per_unit < 1 || acc_per_unit > (1 << (31 - LGC_SWEEP_SHIFT)) ||
-            (int64_t)units * acc_per_unit * cfg.lpr * 16 > LGC_SWEEP_LDS_BYTES)
-            return LGC_E_INVAL;
-        // One launch per PASS, sized to what is resident at once (two 80 KiB panels per CU), so that all
-        // workgroups of a pass start together and walk their band's columns in step; a single oversize
-        // launch lets late workgroups start at column 0 while the others are mid-band (measured: L2 hit
-        // 25 % instead of the shared sweep).
-#ifndef LGC_SWEEP_SPLIT
-#define LGC_SWEEP_SPLIT 1
-#endif
-        const int per_pass = LGC_SWEEP_SPLIT ? std::max(1, (2 * kNumCUs) / n_bands) : panels_per_band;
-        for (int off = 0; off < panels_per_band; off += per_pass) {
-            const int count = std::min(per_pass, panels_per_band - off);
-            SweepArgs sa{pedges, wave_ptr, acc_slot, x, partials, x_stride, n_bands, panels_per_band, acc_per_unit,
-                         dim, cfg.lpr, off};
-            hipLaunchKernelGGL(k_spmm_sweep, dim3(n_bands * count), dim3(kSweepThreads), 0, stream, sa);
-        }
-    }
-    if (n_multi > 0) {
-        SpmmArgs p{nullptr, nullptr, x, y, r, x_stride, y_stride, r_stride, a, b, dim, cfg.lpr, 0, 0, 0, nullptr, 0, 0};
-        p.wt_store = (table_rows * y_stride * 4 < (int64_t(1) << 32)) ? 1 : 0;
-        const int blocks = ceil_div(n_multi, kBlock / kWave);
-        if (cfg.vec == 4)
-            hipLaunchKernelGGL((k_spmm_combine<4>), dim3(blocks), dim3(kBlock), 0, stream, p, multi, n_multi, partials);
-        else
-            hipLaunchKernelGGL((k_spmm_combine<1>), dim3(blocks), dim3(kBlock), 0, stream, p, multi, n_multi, partials);
-    }
-    return (int)hipGetLastError();
 }
 
 int lgc_axpby(float *y, int64_t y_stride, const float *r, int64_t r_stride, float a, float b, int64_t n_rows,

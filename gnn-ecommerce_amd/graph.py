@@ -89,140 +89,6 @@ def build_row_plan(rowptr: Tensor, row_begin: int, row_end: int,
     return RowPlan(row_begin, row_end, short_max, chunks, multi, int(mnch.sum().item()))
 
 
-SWEEP_SHIFT = 27          # column id bits in a packed panel entry (LGC_SWEEP_SHIFT)
-SWEEP_LDS_BYTES = 81920   # LGC_SWEEP_LDS_BYTES: LDS image of one panel (two panels per CU)
-SWEEP_WAVES = 16          # wavefronts of a panel's workgroup
-SWEEP_BANDS = int(os.environ.get("LGCN_SWEEP_BANDS", "8"))      # column bands = XCDs of an MI355X
-SWEEP_PIECE = int(os.environ.get("LGCN_SWEEP_PIECE", "128"))   # longest run of entries one accumulator takes
-USE_SWEEP = os.environ.get("LGCN_SWEEP", "1") == "1"
-
-
-@dataclass
-class SweepPlan:
-    """Work decomposition of the long rows for ``lgc_spmm_sweep`` (see include/lgconv_hip.h)."""
-    pedges: Tensor          # int32 [P, 2]: column | accumulator-in-unit << 27, fp32 bits of the value
-    wave_ptr: Tensor        # int32 [n_panels * 16 + 1]
-    acc_slot: Tensor        # int32 [n_panels * 16 * groups * acc_per_unit]
-    acc_per_unit: int
-    lpr: int                # lanes per row the lists were laid out for
-    multi: Tensor           # int32 [M, 4]: row, slot_begin, slot_end, 0
-    n_bands: int
-    panels_per_band: int
-    n_slots: int
-
-
-def sweep_geometry(dim: int) -> Tuple[int, int, int, int]:
-    """(lanes per row, lane groups per wavefront, entries per group and batch, accumulators per unit)."""
-    lpr = (dim + 3) // 4
-    groups = 64 // lpr
-    per = 64 // groups
-    apu = min(SWEEP_LDS_BYTES // (SWEEP_WAVES * groups * lpr * 16), 1 << (31 - SWEEP_SHIFT))
-    return lpr, groups, per, apu
-
-
-def build_sweep_plan(rowptr: Tensor, entries: Tensor, row_begin: int, row_end: int, short_max: int,
-                     dim: int, n_bands: int = SWEEP_BANDS, piece: int = SWEEP_PIECE) -> Optional[SweepPlan]:
-    """Pure index arithmetic on ``rowptr.device`` (unit-tested on CPU).
-
-    Every entry of a row longer than ``short_max`` in [row_begin, row_end) is given to one *accumulator*
-    = (column band, row, run of at most ``piece`` entries in column order).  Bands cut the column range
-    into ``n_bands`` parts with equal numbers of such entries.  Inside a band the accumulators are sorted
-    by size and dealt in snake order to the band's *units* (one lane group of one wavefront of one panel),
-    ``acc_per_unit`` each at most, so units carry equal work; a unit's entries are then sorted by column
-    and laid out the way the kernel reads them (batches of 64 per wavefront, a slice per lane group).
-    Slots (one per accumulator) are numbered by (row, band, run): a row's slots are consecutive and the
-    combine kernel adds them in that fixed order.
-    """
-    dev = rowptr.device
-    n = rowptr.numel() - 1
-    lpr, groups, per, apu = sweep_geometry(dim)
-    if n >= (1 << SWEEP_SHIFT) or dim < 4 or apu < 1:
-        return None
-    rp = rowptr.to(torch.int64)
-    deg = rp[1:] - rp[:-1]
-    swept = torch.zeros(n, dtype=torch.bool, device=dev)
-    swept[row_begin:row_end] = deg[row_begin:row_end] > short_max
-    if not bool(swept.any().item()):
-        return None
-    row_of = torch.repeat_interleave(torch.arange(n, device=dev), deg)
-    e_idx = torch.nonzero(swept[row_of]).flatten()
-    r = row_of[e_idx]
-    c = entries[e_idx, 0].to(torch.int64)
-    v = entries[e_idx, 1]
-    total = e_idx.numel()
-    # column bands with equal entry counts
-    csum = torch.cumsum(torch.bincount(c, minlength=n), 0)
-    targets = torch.tensor([(total * k) // n_bands for k in range(1, n_bands)], dtype=torch.int64, device=dev)
-    cuts = torch.searchsorted(csum, targets, right=False) + 1          # first column of bands 1..n_bands-1
-    band = torch.bucketize(c, cuts, right=True)
-    # accumulators: runs of <= piece entries of one (band, row) in column order
-    order = torch.argsort((band * n + r) * n + c)
-    band, r, c, v = band[order], r[order], c[order], v[order]
-    pos = torch.arange(total, device=dev)
-    task_first = torch.ones(total, dtype=torch.bool, device=dev)
-    task_first[1:] = (band[1:] != band[:-1]) | (r[1:] != r[:-1])
-    task_start = pos[task_first][torch.cumsum(task_first.to(torch.int64), 0) - 1]
-    acc_first = task_first | ((pos - task_start) % piece == 0)
-    acc_id = torch.cumsum(acc_first.to(torch.int64), 0) - 1
-    n_acc = int(acc_id[-1].item()) + 1
-    acc_size = torch.bincount(acc_id, minlength=n_acc)
-    acc_band, acc_row = band[acc_first], r[acc_first]
-    # slots by (row, band, run) -- accumulators are in (band, row, run) order now
-    slot_order = torch.argsort(acc_row * n_bands + acc_band, stable=True)
-    acc_slot_id = torch.empty(n_acc, dtype=torch.int64, device=dev)
-    acc_slot_id[slot_order] = torch.arange(n_acc, device=dev)
-    rows_sorted = acc_row[slot_order]
-    row_first = torch.ones(n_acc, dtype=torch.bool, device=dev)
-    row_first[1:] = rows_sorted[1:] != rows_sorted[:-1]
-    slot_begin = torch.nonzero(row_first).flatten()
-    slot_end = torch.cat([slot_begin[1:], torch.tensor([n_acc], device=dev)])
-    multi = torch.stack([rows_sorted[row_first], slot_begin, slot_end, torch.zeros_like(slot_begin)], dim=1)
-    # deal accumulators to units: inside a band by descending size, snake order
-    upp = SWEEP_WAVES * groups                                       # units per panel
-    per_band = torch.bincount(acc_band, minlength=n_bands)
-    band_start = torch.cumsum(per_band, 0) - per_band
-    ppb = int(((per_band + apu * upp - 1) // (apu * upp)).max().item())
-    units_band = ppb * upp
-    by_size = torch.argsort(acc_band * (total + 1) + (total - acc_size))
-    q = torch.arange(n_acc, device=dev) - band_start[acc_band[by_size]]
-    rnd, u_in = q // units_band, q % units_band
-    u_in = torch.where(rnd % 2 == 0, u_in, units_band - 1 - u_in)
-    acc_unit = torch.empty(n_acc, dtype=torch.int64, device=dev)
-    acc_local = torch.empty(n_acc, dtype=torch.int64, device=dev)
-    acc_unit[by_size] = acc_band[by_size] * units_band + u_in
-    acc_local[by_size] = rnd
-    n_units = n_bands * units_band
-    acc_slot = torch.full((n_units * apu,), -1, dtype=torch.int32, device=dev)
-    acc_slot[acc_unit * apu + acc_local] = acc_slot_id.to(torch.int32)
-    # unit entry lists by column, laid out per wavefront: batch b, positions [g*per, (g+1)*per) = group g
-    e_unit = acc_unit[acc_id]
-    packed = c | (acc_local[acc_id] << SWEEP_SHIFT)
-    order2 = torch.argsort(e_unit * n + c, stable=True)
-    e_unit, packed, v = e_unit[order2], packed[order2], v[order2]
-    cnt = torch.bincount(e_unit, minlength=n_units)
-    n_waves = n_units // groups
-    batches = ((cnt + per - 1) // per).view(n_waves, groups).max(dim=1).values
-    wave_len = batches * 64
-    wave_base = torch.cumsum(wave_len, 0) - wave_len
-    n_out = int(wave_len.sum().item())
-    unit_start = torch.cumsum(cnt, 0) - cnt
-    k = torch.arange(total, device=dev) - unit_start[e_unit]
-    dest = wave_base[e_unit // groups] + (k // per) * 64 + (e_unit % groups) * per + (k % per)
-    # padding: zero-valued copy of the unit's last entry (an idle lane / an empty unit: row 0, accumulator 0)
-    last = torch.zeros(n_units, dtype=torch.int64, device=dev)
-    nonempty = cnt > 0
-    last[nonempty] = packed[(unit_start + cnt - 1)[nonempty]]
-    wave_of = torch.repeat_interleave(torch.arange(n_waves, device=dev), wave_len)
-    in_batch = (torch.arange(n_out, device=dev) - wave_base[wave_of]) % 64
-    pedges = torch.zeros((n_out, 2), dtype=torch.int32, device=dev)
-    pedges[:, 0] = last[wave_of * groups + torch.clamp(in_batch // per, max=groups - 1)].to(torch.int32)
-    pedges[dest, 0] = packed.to(torch.int32)
-    pedges[dest, 1] = v
-    wave_ptr = torch.cat([wave_base, wave_base[-1:] + wave_len[-1:]]).to(torch.int32)
-    return SweepPlan(pedges.contiguous(), wave_ptr.contiguous(), acc_slot.contiguous(), apu, lpr,
-                     multi.to(torch.int32).contiguous(), n_bands, ppb, n_acc)
-
-
 @dataclass
 class Operator:
     """One sparse operator ready to be applied: CSR + plan (+ per-width scratch)."""
@@ -232,8 +98,6 @@ class Operator:
     plan: RowPlan
     slab: Optional[Tensor] = None        # int32 [n_rows * W, 2]: heads of every row, padded (lgc_build_slab)
     slab_width: int = 0
-    use_sweep: bool = False              # long rows by lgc_spmm_sweep instead of the chunk list
-    _sweeps: Dict[int, Optional[SweepPlan]] = field(default_factory=dict)   # per accumulator capacity
     _partials: Dict[int, Tensor] = field(default_factory=dict)
 
     @property
@@ -241,7 +105,7 @@ class Operator:
         return self.entries.size(0)
 
     def partials(self, dim: int) -> Optional[Tensor]:
-        n_slots = max([self.plan.n_slots] + [sp.n_slots for sp in self._sweeps.values() if sp is not None])
+        n_slots = self.plan.n_slots
         if n_slots == 0:
             return None
         buf = self._partials.get(dim)
@@ -249,16 +113,6 @@ class Operator:
             buf = torch.empty((n_slots, dim), dtype=torch.float32, device=self.rowptr.device)
             self._partials[dim] = buf
         return buf
-
-    def sweep_plan(self, dim: int) -> Optional[SweepPlan]:
-        """The sweep work list for this width (its layout follows the lane-group geometry), built on first use."""
-        if not self.use_sweep or dim < 4 or self.n_rows >= (1 << SWEEP_SHIFT) or self.plan.n_chunks == 0:
-            return None
-        key = (dim + 3) // 4
-        if key not in self._sweeps:
-            self._sweeps[key] = build_sweep_plan(self.rowptr, self.entries, self.plan.row_begin, self.plan.row_end,
-                                                 self.plan.short_max, dim)
-        return self._sweeps[key]
 
     def values(self) -> Tensor:
         return self.entries[:, 1].view(torch.float32)
@@ -281,31 +135,14 @@ class Operator:
         if not lib.lgc_dim_ok(dim):
             raise _native.NativeLibraryError(f"embedding width {dim} is not supported by the HIP kernels")
         p = self.plan
-        sw = self.sweep_plan(dim)
         partials = self.partials(dim)
         table_rows = min(x.size(0), out.size(0))
-        if sw is not None:
-            with torch.cuda.device(x.device):
-                stream = _native.stream_of(x.device)
-                code = lib.lgc_spmm(
-                    _native.ptr(self.rowptr), _native.ptr(self.entries), p.row_begin, p.row_end, p.short_max,
-                    None, 0, None, 0, None, _native.ptr(self.slab), self.slab_width, table_rows,
-                    _native.ptr(x), x.stride(0), _native.ptr(out), out.stride(0),
-                    _native.ptr(r), 0 if r is None else r.stride(0), float(a), float(b), dim, stream)
-                _native.check(code, "lgc_spmm")
-                code = lib.lgc_spmm_sweep(
-                    _native.ptr(sw.pedges), _native.ptr(sw.wave_ptr), _native.ptr(sw.acc_slot), sw.n_bands,
-                    sw.panels_per_band, sw.acc_per_unit, _native.ptr(sw.multi), sw.multi.size(0), _native.ptr(partials), table_rows,
-                    _native.ptr(x), x.stride(0), _native.ptr(out), out.stride(0),
-                    _native.ptr(r), 0 if r is None else r.stride(0), float(a), float(b), dim, stream)
-            _native.check(code, "lgc_spmm_sweep")
-            return out
         with torch.cuda.device(x.device):
             code = lib.lgc_spmm(
                 _native.ptr(self.rowptr), _native.ptr(self.entries), p.row_begin, p.row_end, p.short_max,
                 _native.ptr(p.chunks) if p.n_chunks else None, p.n_chunks,
                 _native.ptr(p.multi) if p.n_multi else None, p.n_multi, _native.ptr(partials),
-                _native.ptr(self.slab), self.slab_width, min(x.size(0), out.size(0)),
+                _native.ptr(self.slab), self.slab_width, table_rows,
                 _native.ptr(x), x.stride(0), _native.ptr(out), out.stride(0),
                 _native.ptr(r), 0 if r is None else r.stride(0), float(a), float(b), dim,
                 _native.stream_of(x.device))
@@ -387,7 +224,7 @@ class PropGraph:
                 code = lib.lgc_build_slab(_native.ptr(rowptr), _native.ptr(entries), n, width, _native.ptr(slab),
                                           _native.stream_of(self.device))
             _native.check(code, "lgc_build_slab")
-        return Operator(n, rowptr, entries, plan, slab, width, USE_SWEEP)
+        return Operator(n, rowptr, entries, plan, slab, width)
 
     def _find_bipartite_split(self) -> Optional[int]:
         """s such that every edge joins a node < s ("users") with a node >= s ("items") -- the layout of
@@ -409,7 +246,7 @@ class PropGraph:
             op = self.transpose_op if transpose else self.forward_op
             got = tuple(Operator(op.n_rows, op.rowptr, op.entries,
                                  build_row_plan(op.rowptr, lo, hi, self.short_max, self.chunk_len),
-                                 op.slab, op.slab_width, op.use_sweep)
+                                 op.slab, op.slab_width)
                         for lo, hi in ((0, self.split), (self.split, self.num_nodes)))
             self._halves[transpose] = got
         return got

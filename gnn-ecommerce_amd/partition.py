@@ -72,8 +72,7 @@ class HipOps:
     def restrict(self, op: Operator, row_begin: int, row_end: int) -> Operator:
         """The same CSR, work plan limited to rows [row_begin, row_end)."""
         return Operator(op.n_rows, op.rowptr, op.entries,
-                        build_row_plan(op.rowptr, row_begin, row_end, SHORT_MAX, CHUNK_LEN), op.slab, op.slab_width,
-                        op.use_sweep)
+                        build_row_plan(op.rowptr, row_begin, row_end, SHORT_MAX, CHUNK_LEN), op.slab, op.slab_width)
 
     def apply(self, op: Operator, x: Tensor, out: Tensor, a: float, r: Optional[Tensor], b: float) -> None:
         op.apply(x, out, a=a, r=r, b=b)

@@ -144,43 +144,6 @@ int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries,
              const float *r, int64_t r_stride,
              float a, float b, int32_t dim, void *stream);
 
-/* ---------------------------------------------------------------------------------------
- * Long rows by a column-ordered SWEEP with LDS-resident accumulators (an alternative to the `chunks`
- * work list of lgc_spmm for the same rows; same replaced reference code: the gather / scatter-add of one
- * LGConv layer, src/lightgcn.py:96).
- *
- * The columns (source rows of x) are cut into `n_bands` bands; block b works on band b % n_bands, so
- * that -- with the round-robin block placement observed on MI355X -- one XCD sweeps one band.  A *panel*
- * is the work of one 1024-thread workgroup (80 KiB of LDS, two per CU).  Inside it every lane group
- * (G = 64 / ceil(dim/4) per wavefront, 16 wavefronts) is a *unit*: it owns `acc_per_unit` accumulators
- * (each one output row's partial sum over a run of the band's columns) and the list of the entries that
- * feed them, sorted by column.  All units of a band walk the band's columns in the same order, so a
- * source row is fetched across the fabric about once per band and pass and then served by that XCD's
- * L2 to the other units that need it (measured: DESIGN.md section 5).  Each accumulator ends in
- * partials[slot]; `multi` rows are then summed in slot order by the same combine kernel lgc_spmm uses
- * (epilogue a, b, r applied there).  No atomics: results are independent of placement and scheduling.
- *
- *   pedges      lgc_entry lists, one per wavefront: batches of 64 entries in which positions
- *               [g*per, (g+1)*per), per = 64 / G, are the next entries of lane group g; col = source row |
- *               (accumulator index inside the unit << LGC_SWEEP_SHIFT); short lists are padded with
- *               zero-valued copies of a unit's last entry
- *   wave_ptr    int32 [n_panels * 16 + 1]: entry offsets of the wavefront lists, panels laid out
- *               [band][panels_per_band]
- *   acc_slot    int32 [n_panels * 16 * G * acc_per_unit]: partial slot of each accumulator, -1 = unused
- *   acc_per_unit  16 * G * acc_per_unit * 16 * ceil(dim/4) <= LGC_SWEEP_LDS_BYTES, <= 1 << (31 - LGC_SWEEP_SHIFT)
- *   dim         >= 4;  table_rows < 1 << LGC_SWEEP_SHIFT
- * ------------------------------------------------------------------------------------- */
-#define LGC_SWEEP_SHIFT     27
-#define LGC_SWEEP_LDS_BYTES 81920
-int lgc_spmm_sweep(const lgc_entry *pedges, const int32_t *wave_ptr, const int32_t *acc_slot,
-                   int32_t n_bands, int32_t panels_per_band, int32_t acc_per_unit,
-                   const lgc_multi_row *multi, int32_t n_multi, float *partials,
-                   int64_t table_rows,
-                   const float *x, int64_t x_stride,
-                   float *y, int64_t y_stride,
-                   const float *r, int64_t r_stride,
-                   float a, float b, int32_t dim, void *stream);
-
 /* y[i, :dim] = a * y[i, :dim] + b * r[i, :dim]  for i < n_rows (epilogue after an exchange). */
 int lgc_axpby(float *y, int64_t y_stride, const float *r, int64_t r_stride,
               float a, float b, int64_t n_rows, int32_t dim, void *stream);
