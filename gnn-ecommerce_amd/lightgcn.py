@@ -53,6 +53,10 @@ class LightGCN(torch.nn.Module):
         self.embedding = torch.nn.Embedding(num_nodes, embedding_dim)
         self.convs = torch.nn.ModuleList(LGConv(**kwargs) for _ in range(num_layers))
         self._alpha_host = None
+        # serving: recommendK reuses the propagated table while neither the graph, the
+        # weights nor alpha changed; set to False to recompute on every request like the reference
+        self.cache_recommend_embeddings = True
+        self._served = None
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -76,6 +80,23 @@ class LightGCN(torch.nn.Module):
         normalize = self.convs[0].normalize if self.num_layers > 0 else True
         graph = get_graph(edge_index, edge_weight, self.num_nodes, normalize)
         return propagate_sum(x0, graph, self._alphas())
+
+    def _serving_embedding(self, edge_index, edge_weight) -> Tensor:
+        """The propagated table for read-only use by ``recommendK``.
+
+        Upstream recomputes all K layers for every request (torchserve/lightgcn_handler.py:91 ->
+        src/lightgcn.py:171) although, with gradients off, the result depends only on the graph, the weight
+        table and alpha.  It is kept here until one of them changes (tensor identity + version counter; an
+        optimizer step or load_state_dict bumps the weight's version)."""
+        w = self.embedding.weight
+        if torch.is_grad_enabled() or not self.cache_recommend_embeddings:
+            return self.get_embedding(edge_index, edge_weight)
+        normalize = self.convs[0].normalize if self.num_layers > 0 else True
+        graph = get_graph(edge_index, edge_weight, self.num_nodes, normalize)
+        key = (id(graph), w.data_ptr(), w._version, w.device, self._alphas())
+        if self._served is None or self._served[0] != key:
+            self._served = (key, graph, self.get_embedding(edge_index, edge_weight))
+        return self._served[2]
 
     def forward(self, edge_index, edge_label_index: Optional[Tensor] = None,
                 edge_weight: Optional[Tensor] = None) -> Tensor:
@@ -111,7 +132,7 @@ class LightGCN(torch.nn.Module):
         """Top-k unseen items per user as the DataFrame src/lightgcn.py:169-182 returns
         (columns ``user_ID``, ``top_rlvnt_itm``); seen items are zeroed, not removed, as upstream."""
         import pandas as pd
-        embeds = self.get_embedding(edge_index, edge_weight)
+        embeds = self._serving_embedding(edge_index, edge_weight)
         users, items = torch.split(embeds, [n_users, n_items])
         pred = (users[user_id_list] @ items.t()).cpu()
         top_index = torch.mul(pred, (1 - interactions_t)).topk(k, dim=-1).indices

@@ -114,41 +114,66 @@ class PartitionedPropagator:
         self.local_nnz = int(mine.sum().item()) * 2
         self._keep = (full, local)
 
-    # -- one hop -----------------------------------------------------------------------------
-    def hop(self, x: Tensor, out: Tensor, a: float, r: Optional[Tensor], b: float) -> Tensor:
-        from . import propagate
-        log = propagate.HOP_EVENT_LOG if x.is_cuda else None
-        if log is not None:
-            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            start.record()
-        self._hop(x, out, a, r, b)
-        if log is not None:
-            end.record()
-            log.append((start, end))
-        return out
-
-    def _hop(self, x: Tensor, out: Tensor, a: float, r: Optional[Tensor], b: float) -> None:
-        items_out = out[self.n_users:]
+    # -- hops ----------------------------------------------------------------------------------
+    # A hop has three local pieces and one exchange:
+    #   item step   partial sums for all item rows from this rank's user rows of x
+    #   exchange    all-reduce of the item block (in place in ``out``)
+    #   user step   this rank's user rows of ``out`` from the (replicated) item rows of x
+    #   finish      epilogue a, b, r on the reduced item block
+    # Only the user step of the NEXT hop needs the reduced item block; the next hop's item step needs
+    # just this rank's own user rows.  propagate_sum therefore keeps the all-reduce of hop l in flight
+    # across hop l's user step and hop l+1's item step and waits for it right before hop l+1's user step.
+    def _item_step(self, x: Tensor, out: Tensor):
         self.ops.apply(self.item_op, x, out, 1.0, None, 0.0)                 # raw partial sums
-        work = None
         if self.world > 1:
-            work = dist.all_reduce(items_out, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self.ops.apply(self.user_op, x, out, a, r, b)                        # overlaps the exchange
+            return dist.all_reduce(out[self.n_users:], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return None
+
+    def _finish_items(self, work, out: Tensor, a: float, r: Optional[Tensor], b: float) -> None:
         if work is not None:
             work.wait()
         if a != 1.0 or r is not None:
-            self.ops.axpby(items_out, None if r is None else r[self.n_users:], a, b)
+            self.ops.axpby(out[self.n_users:], None if r is None else r[self.n_users:], a, b)
+
+    def hop(self, x: Tensor, out: Tensor, a: float, r: Optional[Tensor], b: float) -> Tensor:
+        """One complete hop (used on its own by tests and by callers that need a single LGConv)."""
+        work = self._item_step(x, out)
+        self.ops.apply(self.user_op, x, out, a, r, b)                        # overlaps the exchange
+        self._finish_items(work, out, a, r, b)
+        return out
 
     def propagate_sum(self, x0: Tensor, alphas: Sequence[float]) -> Tensor:
         """Horner form of sum_l alpha_l A^l x0 (see propagate.py); valid rows of the result: own users + items."""
+        from . import propagate
         k = len(alphas) - 1
         if k == 0:
             return x0 * alphas[0]
         x0 = x0.contiguous()
-        h = self.hop(x0, torch.empty_like(x0), alphas[k], x0, alphas[k - 1])
-        for layer in range(k - 2, -1, -1):
-            h = self.hop(h, torch.empty_like(x0), 1.0, x0, alphas[layer])
-        return h
+        log = propagate.HOP_EVENT_LOG if x0.is_cuda else None
+        # hop j (j = 0 .. k-1) maps h_in -> h_out with epilogue (a_j, b_j, r = x0)
+        coef = [(alphas[k], alphas[k - 1])] + [(1.0, alphas[layer]) for layer in range(k - 2, -1, -1)]
+        h_in, h_out = x0, torch.empty_like(x0)
+        pending = None                                   # (work, table, a, b) of the previous hop's item block
+        marks = []
+        for j, (a, b) in enumerate(coef):
+            if log is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks.append(ev)
+            work = self._item_step(h_in, h_out)          # needs only OWN user rows of h_in
+            if pending is not None:                      # now the previous hop's item block is needed
+                self._finish_items(*pending)
+            self.ops.apply(self.user_op, h_in, h_out, a, x0, b)
+            pending = (work, h_out, a, x0, b)
+            if j + 1 < k:
+                h_in, h_out = h_out, torch.empty_like(x0)
+        self._finish_items(*pending)
+        if log is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append(ev)
+            log.extend(zip(marks[:-1], marks[1:]))
+        return h_out
 
     def gather_users(self, table: Tensor) -> Tensor:
         """Fill every rank's user rows of ``table`` from their owners (all ranks end with the full table)."""
