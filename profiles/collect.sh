@@ -15,4 +15,6 @@ mkdir -p "$out"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py "${args[@]}" > "$out/trace.log" 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 bench.py "${args[@]}" > "$out/pmc_fetch.log" 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$out/pmc_write" -- python3 bench.py "${args[@]}" > "$out/pmc_write.log" 2>&1 || exit 1
-python3 profiles/summarize.py "$out" > "$out/summary.json" && cat "$out/summary.json"
+# hops profiled per pass = (steps + warmup) * layers of the bench.py arguments above (defaults: 12 * 3)
+hops=${HOPS:-36}
+python3 profiles/summarize.py "$out" "$hops" > "$out/summary.json" && cat "$out/summary.json"

@@ -36,7 +36,10 @@ def counters(d, sub):
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
 
 
-def main(d):
+HOP_KERNELS = ("k_spmm_rows", "k_spmm_chunks", "k_spmm_combine", "k_lincomb")
+
+
+def main(d, n_hops=0):
     stats = kernel_stats(d)
     pmc = defaultdict(dict)
     for sub in ("pmc_fetch", "pmc_write"):
@@ -57,8 +60,16 @@ def main(d):
             e["l2_hit_rate"] = c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1.0)
             e["l2_requests"] = c["TCC_HIT_sum"] + c["TCC_MISS_sum"]
         res[k] = e
+    if n_hops:
+        # one hop = every launch of the propagation kernels divided by the number of hops profiled
+        hop = {"n_hops": n_hops, "kernel_us": 0.0, "hbm_bytes": 0.0}
+        for k, e in res.items():
+            if k.startswith(HOP_KERNELS):
+                hop["kernel_us"] += e["calls"] * e["avg_us"] / n_hops
+                hop["hbm_bytes"] += e["calls"] * (e.get("fetch_bytes_x2", 0.0) + e.get("write_bytes", 0.0)) / n_hops
+        res["per_hop"] = hop
     print(json.dumps(res, indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 0)
