@@ -158,7 +158,7 @@ def main():
                        "graph_build_s": round(t_build, 3), "synth_gen_s": round(t_gen, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic,
-                         "kernel": "one hop = lgc_spmm (k_spmm_rows + k_spmm_chunks + k_spmm_combine)",
+                         "kernel": "one hop = one LGConv layer: k_spmm_hop (chunk + row parts) + k_spmm_combine per operator half",
                          "algorithmic_bytes_per_launch": bmin, "launch_ms": hop_mean_s * 1e3,
                          "launches_timed": len(hop_ms)},
         }

@@ -34,7 +34,6 @@ SIGNATURES = {
     "lgc_spmm": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32,
                          c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float, c_float,
                          c_int32, c_void_p]),
-    "lgc_axpby": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_float, c_float, c_int64, c_int32, c_void_p]),
     "lgc_lincomb": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p]),
     "lgc_pair_dot": (c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                              c_void_p, c_void_p]),

@@ -10,11 +10,13 @@
 //
 // Kernels
 //   k_build_*        one-time COO -> CSR (+ reference-order fp32 degree, normalised values)
-//   k_spmm_rows      rows with <= short_max entries, one lane group per row, entry order
-//   k_spmm_chunks    one wavefront per chunk of a long row, lane groups stride the entries,
+//   k_spmm_hop       one launch per operator and hop:
+//       chunk part   one wavefront per chunk of a long row, lane groups stride the entries,
 //                    cross-group reduce through ds_bpermute shuffles
+//       row part     rows with <= short_max entries, one lane group per row, entry order, entries
+//                    fetched through a fixed-width slab of row heads
 //   k_spmm_combine   fixed-order sum of a long row's partial slots + epilogue
-//   k_axpby, k_pair_dot, k_pair_dot_bwd
+//   k_lincomb, k_pair_dot, k_pair_dot_bwd
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -279,18 +281,18 @@ __device__ __forceinline__ void finish_row(const SpmmArgs &p, int64_t row, int c
 // Short rows: one lane group per row, entries in order, 4 gathers in flight per group; the epilogue
 // row is requested before the gathers and consumed after them.
 template <int VEC>
-__global__ __launch_bounds__(kBlock) void k_spmm_rows(SpmmArgs p) {
+__device__ __forceinline__ void rows_body(const SpmmArgs &p, int64_t block) {
     const int lane = threadIdx.x & (kWave - 1);
     const int rows_per_wave = kWave / p.lpr;
     const int g = lane / p.lpr;
     const int l = lane - g * p.lpr;
-    const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x / kWave);
+    const int64_t wave = block * (kBlock / kWave) + (threadIdx.x / kWave);
     const int64_t row = (int64_t)p.row_begin + wave * rows_per_wave + g;
     if (g >= rows_per_wave || row >= p.row_end) return;
     const int c0 = lane_column<VEC>(l, p.dim);
 
     const int32_t s = p.rowptr[row], e = p.rowptr[row + 1];
-    if (e - s > p.short_max) return;  // belongs to k_spmm_chunks
+    if (e - s > p.short_max) return;  // belongs to the chunk part
 
     const float *xb = p.x + c0;
     const lgc_entry *__restrict__ ent = p.entries;
@@ -337,12 +339,12 @@ __global__ void k_build_slab(const int32_t *__restrict__ rowptr, const lgc_entry
 // broadcasts entry after entry with ds_bpermute and gathers.  Round trips per row: slab -> gathers ->
 // store, instead of rowptr -> entries -> gathers -> store.  Entry order is unchanged (bit-exact sums).
 template <int VEC, int W>
-__global__ __launch_bounds__(kBlock) void k_spmm_rows_slab(SpmmArgs p) {
+__device__ __forceinline__ void rows_slab_body(const SpmmArgs &p, int64_t block) {
     const int lane = threadIdx.x & (kWave - 1);
     const int rows_per_wave = kWave / p.lpr;
     const int g = lane / p.lpr;
     const int l = lane - g * p.lpr;
-    const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x / kWave);
+    const int64_t wave = block * (kBlock / kWave) + (threadIdx.x / kWave);
     const int64_t row = (int64_t)p.row_begin + wave * rows_per_wave + g;
     const bool valid = g < rows_per_wave && row < p.row_end;
     const int c0 = lane_column<VEC>(l, p.dim);
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(kBlock) void k_spmm_rows_slab(SpmmArgs p) {
         e = p.rowptr[row + 1];
         if (p.r != nullptr) rv = load_row<VEC>(p.r + row * p.r_stride + c0);
     }
-    const bool mine_row = valid && (e - s) <= p.short_max;   // longer rows belong to k_spmm_chunks
+    const bool mine_row = valid && (e - s) <= p.short_max;   // longer rows belong to the chunk part
     const int32_t n_head = mine_row ? min(e - s, W) : 0;
     const float *xb = p.x + c0;
 #pragma unroll
@@ -409,10 +411,10 @@ __global__ __launch_bounds__(kBlock) void k_spmm_rows_slab(SpmmArgs p) {
 // Long rows: one wavefront per chunk.  Lane group g takes entries begin+g, begin+g+G, ...;
 // the G group sums are then added in group order by lane group 0.
 template <int VEC>
-__global__ __launch_bounds__(kBlock) void k_spmm_chunks(SpmmArgs p, const lgc_chunk *__restrict__ chunks,
-                                                       int32_t n_chunks, float *__restrict__ partials) {
+__device__ __forceinline__ void chunks_body(const SpmmArgs &p, const lgc_chunk *__restrict__ chunks, int32_t n_chunks,
+                                            float *__restrict__ partials, int64_t block) {
     const int lane = threadIdx.x & (kWave - 1);
-    const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x / kWave);
+    const int64_t wave = block * (kBlock / kWave) + (threadIdx.x / kWave);
     if (wave >= n_chunks) return;  // wave-uniform
     const lgc_chunk ch = chunks[wave];
     const int groups = kWave / p.lpr;
@@ -486,6 +488,23 @@ __global__ __launch_bounds__(kBlock) void k_spmm_chunks(SpmmArgs p, const lgc_ch
     }
 }
 
+// One launch per operator and hop: the first `chunk_blocks` workgroups take the chunk work list (long rows
+// are dispatched first, they run longest), the rest the short rows.  Launching the two parts separately
+// left each one's ramp-up and tail exposed -- 7 back-to-back launches per hop of 4-45 us each on a rank of
+// an 8-way partition.  W = 0: short rows read their entries through rowptr (no slab for this width).
+template <int VEC, int W>
+__global__ __launch_bounds__(kBlock) void k_spmm_hop(SpmmArgs p, const lgc_chunk *__restrict__ chunks,
+                                                    int32_t n_chunks, float *__restrict__ partials,
+                                                    int32_t chunk_blocks) {
+    if ((int32_t)blockIdx.x < chunk_blocks) {
+        chunks_body<VEC>(p, chunks, n_chunks, partials, blockIdx.x);
+    } else {
+        const int64_t block = (int64_t)blockIdx.x - chunk_blocks;
+        if constexpr (W == 0) rows_body<VEC>(p, block);
+        else rows_slab_body<VEC, W>(p, block);
+    }
+}
+
 // Rows cut into several chunks: one wavefront per row.  Lane group g adds slots g, g+G, g+2G, ...
 // (4 loads in flight per group), then the G group sums are added in group order -- a fixed
 // association, so the result does not depend on scheduling.
@@ -533,19 +552,6 @@ __global__ __launch_bounds__(kBlock) void k_spmm_combine(SpmmArgs p, const lgc_m
         rv.zero();
         if (p.r != nullptr) rv = load_row<VEC>(p.r + (int64_t)mr.row * p.r_stride + c0);
         finish_row<VEC>(p, mr.row, c0, acc, rv);
-    }
-}
-
-__global__ void k_axpby(float *__restrict__ y, int64_t y_stride, const float *__restrict__ r, int64_t r_stride,
-                        float a, float b, int64_t n_rows, int32_t dim) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t total = n_rows * dim;
-    for (; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t row = i / dim;
-        int32_t c = (int32_t)(i - row * dim);
-        float v = __fmul_rn(a, y[row * y_stride + c]);
-        if (r) v = __fadd_rn(v, __fmul_rn(b, r[row * r_stride + c]));
-        y[row * y_stride + c] = v;
     }
 }
 
@@ -755,24 +761,22 @@ int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin,
     return dispatch_dim(cfg, [&](auto vec) -> int {
         constexpr int V = decltype(vec)::value;
         const int64_t n_rows = (int64_t)row_end - row_begin;
-        if (n_rows > 0) {
-            int blocks = ceil_div(ceil_div(n_rows, rows_per_wave), waves_per_block);
+        const int row_blocks = n_rows > 0 ? ceil_div(ceil_div(n_rows, rows_per_wave), waves_per_block) : 0;
+        const int chunk_blocks = n_chunks > 0 ? ceil_div(n_chunks, waves_per_block) : 0;
+        const dim3 grid(row_blocks + chunk_blocks);
+        if (grid.x > 0) {
             if constexpr (V == 4) {
                 if (p.slab_width == 4)
-                    hipLaunchKernelGGL((k_spmm_rows_slab<4, 4>), dim3(blocks), dim3(kBlock), 0, stream, p);
+                    hipLaunchKernelGGL((k_spmm_hop<4, 4>), grid, dim3(kBlock), 0, stream, p, chunks, n_chunks, partials, chunk_blocks);
                 else if (p.slab_width == 8)
-                    hipLaunchKernelGGL((k_spmm_rows_slab<4, 8>), dim3(blocks), dim3(kBlock), 0, stream, p);
+                    hipLaunchKernelGGL((k_spmm_hop<4, 8>), grid, dim3(kBlock), 0, stream, p, chunks, n_chunks, partials, chunk_blocks);
                 else if (p.slab_width == 16)
-                    hipLaunchKernelGGL((k_spmm_rows_slab<4, 16>), dim3(blocks), dim3(kBlock), 0, stream, p);
+                    hipLaunchKernelGGL((k_spmm_hop<4, 16>), grid, dim3(kBlock), 0, stream, p, chunks, n_chunks, partials, chunk_blocks);
                 else
-                    hipLaunchKernelGGL((k_spmm_rows<V>), dim3(blocks), dim3(kBlock), 0, stream, p);
+                    hipLaunchKernelGGL((k_spmm_hop<4, 0>), grid, dim3(kBlock), 0, stream, p, chunks, n_chunks, partials, chunk_blocks);
             } else {
-                hipLaunchKernelGGL((k_spmm_rows<V>), dim3(blocks), dim3(kBlock), 0, stream, p);
+                hipLaunchKernelGGL((k_spmm_hop<1, 0>), grid, dim3(kBlock), 0, stream, p, chunks, n_chunks, partials, chunk_blocks);
             }
-        }
-        if (n_chunks > 0) {
-            hipLaunchKernelGGL((k_spmm_chunks<V>), dim3(ceil_div(n_chunks, waves_per_block)), dim3(kBlock), 0,
-                               stream, p, chunks, n_chunks, partials);
         }
         if (n_multi > 0) {
             int blocks = ceil_div(n_multi, waves_per_block);
@@ -781,17 +785,6 @@ int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin,
         }
         return (int)hipGetLastError();
     });
-}
-
-int lgc_axpby(float *y, int64_t y_stride, const float *r, int64_t r_stride, float a, float b, int64_t n_rows,
-              int32_t dim, void *stream_) {
-    if (!y || n_rows < 0 || dim < 1 || y_stride < dim || (r && r_stride < dim)) return LGC_E_INVAL;
-    if (n_rows == 0) return 0;
-    int64_t total = n_rows * dim;
-    int blocks = (int)std::min<int64_t>(ceil_div(total, kBlock), 256 * 8);
-    hipLaunchKernelGGL(k_axpby, dim3(blocks), dim3(kBlock), 0, as_stream(stream_), y, y_stride, r, r_stride, a, b,
-                       n_rows, dim);
-    return (int)hipGetLastError();
 }
 
 int lgc_lincomb(float *y, int64_t y_stride, const float *const *src, const int64_t *src_stride, const float *coef,

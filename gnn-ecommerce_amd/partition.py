@@ -3,13 +3,14 @@
 One process per GPU.  Users are cut into ``world`` contiguous ranges balanced by nnz (not by
 count); the item block of every table is replicated.  One hop on rank p, for its range [u0, u1):
 
-    I-step   partial[i]  = sum over edges (u -> i), u in [u0, u1), of val * x[u]     (all items)
+    I-step   partial[i]  = a * sum over edges (u -> i), u in [u0, u1), of val * x[u]   (all items;
+                           rank 0 adds b * r[i], so the sum over ranks is the finished item block)
     exchange all-reduce(sum) of the contiguous [n_items, D] item block   -- 13.97 MB at D=64
     U-step   y[u]        = a * sum over edges (i -> u) of val * x[i] + b * r[u]      (own users)
-    finish   y[items]    = a * reduced + b * r[items]
 
-The I-step is launched first and its all-reduce runs on RCCL's stream while the U-step (which
-needs only the replicated item rows of x) computes, so the exchange is hidden behind local work.
+The I-step is launched first and its all-reduce runs on RCCL's stream while the U-step (which needs
+only the replicated item rows of x) AND the next hop's I-step (which needs only this rank's own user
+rows) compute, so the exchange is hidden behind local work.
 User rows never leave their owner during propagation; ``gather_users`` assembles the full table
 only when a caller really needs it (the reference's ``get_embedding`` contract).
 
@@ -22,6 +23,7 @@ implementation shipped here is ``HipOps`` -- there is no CPU compute path in the
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -30,6 +32,9 @@ from torch import Tensor
 
 from . import _native
 from .graph import CHUNK_LEN, SHORT_MAX, Operator, PropGraph, build_row_plan
+
+
+ITEM_SHORT_MAX = int(os.environ.get("LGCN_ITEM_SHORT_MAX", "8"))
 
 
 def balanced_user_ranges(user_degree: Tensor, world: int) -> List[Tuple[int, int]]:
@@ -69,20 +74,13 @@ class HipOps:
               keep_edge_values: bool = False) -> PropGraph:
         return PropGraph(edge_index, edge_weight, num_nodes, normalize, keep_edge_values=keep_edge_values)
 
-    def restrict(self, op: Operator, row_begin: int, row_end: int) -> Operator:
+    def restrict(self, op: Operator, row_begin: int, row_end: int, short_max: int = SHORT_MAX) -> Operator:
         """The same CSR, work plan limited to rows [row_begin, row_end)."""
         return Operator(op.n_rows, op.rowptr, op.entries,
-                        build_row_plan(op.rowptr, row_begin, row_end, SHORT_MAX, CHUNK_LEN), op.slab, op.slab_width)
+                        build_row_plan(op.rowptr, row_begin, row_end, short_max, CHUNK_LEN), op.slab, op.slab_width)
 
     def apply(self, op: Operator, x: Tensor, out: Tensor, a: float, r: Optional[Tensor], b: float) -> None:
         op.apply(x, out, a=a, r=r, b=b)
-
-    def axpby(self, y: Tensor, r: Optional[Tensor], a: float, b: float) -> None:
-        lib = _native.load()
-        with torch.cuda.device(y.device):
-            code = lib.lgc_axpby(_native.ptr(y), y.stride(0), _native.ptr(r), 0 if r is None else r.stride(0),
-                                 float(a), float(b), y.size(0), y.size(1), _native.stream_of(y.device))
-        _native.check(code, "lgc_axpby")
 
 
 class PartitionedPropagator:
@@ -110,36 +108,39 @@ class PartitionedPropagator:
         mine = (dst >= n_users) & (src >= self.u0) & (src < self.u1)
         local = self.ops.build(edge_index[:, mine].contiguous(), full.edge_values[mine].contiguous(), n,
                                normalize=False)
-        self.item_op = self.ops.restrict(local.forward_op, n_users, n)
+        # A rank's slice of an item row is short (mean degree / world entries) but there are only n_items
+        # of them: one wavefront per row (the chunk kernel, 16 gathers in flight) beats one lane group per
+        # row there, so only rows that fit the slab stay on the short-row kernel.
+        self.item_op = self.ops.restrict(local.forward_op, n_users, n, ITEM_SHORT_MAX)
         self.local_nnz = int(mine.sum().item()) * 2
         self._keep = (full, local)
 
     # -- hops ----------------------------------------------------------------------------------
-    # A hop has three local pieces and one exchange:
-    #   item step   partial sums for all item rows from this rank's user rows of x
+    # A hop has two local pieces and one exchange:
+    #   item step   a * (partial sums for all item rows from this rank's user rows of x); rank 0 also adds
+    #               the epilogue term b * r[items], so that the SUM over ranks is the finished item block
+    #               (the exchange is linear: no separate epilogue pass over the item block afterwards)
     #   exchange    all-reduce of the item block (in place in ``out``)
     #   user step   this rank's user rows of ``out`` from the (replicated) item rows of x
-    #   finish      epilogue a, b, r on the reduced item block
     # Only the user step of the NEXT hop needs the reduced item block; the next hop's item step needs
     # just this rank's own user rows.  propagate_sum therefore keeps the all-reduce of hop l in flight
     # across hop l's user step and hop l+1's item step and waits for it right before hop l+1's user step.
-    def _item_step(self, x: Tensor, out: Tensor):
-        self.ops.apply(self.item_op, x, out, 1.0, None, 0.0)                 # raw partial sums
+    def _item_step(self, x: Tensor, out: Tensor, a: float, r: Optional[Tensor], b: float):
+        self.ops.apply(self.item_op, x, out, a, r if self.rank == 0 else None, b)
         if self.world > 1:
             return dist.all_reduce(out[self.n_users:], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         return None
 
-    def _finish_items(self, work, out: Tensor, a: float, r: Optional[Tensor], b: float) -> None:
+    @staticmethod
+    def _finish_items(work) -> None:
         if work is not None:
             work.wait()
-        if a != 1.0 or r is not None:
-            self.ops.axpby(out[self.n_users:], None if r is None else r[self.n_users:], a, b)
 
     def hop(self, x: Tensor, out: Tensor, a: float, r: Optional[Tensor], b: float) -> Tensor:
         """One complete hop (used on its own by tests and by callers that need a single LGConv)."""
-        work = self._item_step(x, out)
+        work = self._item_step(x, out, a, r, b)
         self.ops.apply(self.user_op, x, out, a, r, b)                        # overlaps the exchange
-        self._finish_items(work, out, a, r, b)
+        self._finish_items(work)
         return out
 
     def propagate_sum(self, x0: Tensor, alphas: Sequence[float]) -> Tensor:
@@ -153,21 +154,20 @@ class PartitionedPropagator:
         # hop j (j = 0 .. k-1) maps h_in -> h_out with epilogue (a_j, b_j, r = x0)
         coef = [(alphas[k], alphas[k - 1])] + [(1.0, alphas[layer]) for layer in range(k - 2, -1, -1)]
         h_in, h_out = x0, torch.empty_like(x0)
-        pending = None                                   # (work, table, a, b) of the previous hop's item block
+        pending = None                                   # exchange of the previous hop's item block
         marks = []
         for j, (a, b) in enumerate(coef):
             if log is not None:
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record()
                 marks.append(ev)
-            work = self._item_step(h_in, h_out)          # needs only OWN user rows of h_in
-            if pending is not None:                      # now the previous hop's item block is needed
-                self._finish_items(*pending)
+            work = self._item_step(h_in, h_out, a, x0, b)   # needs only OWN user rows of h_in
+            self._finish_items(pending)                  # now the previous hop's item block is needed
             self.ops.apply(self.user_op, h_in, h_out, a, x0, b)
-            pending = (work, h_out, a, x0, b)
+            pending = work
             if j + 1 < k:
                 h_in, h_out = h_out, torch.empty_like(x0)
-        self._finish_items(*pending)
+        self._finish_items(pending)
         if log is not None:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()

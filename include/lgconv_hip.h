@@ -144,10 +144,6 @@ int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries,
              const float *r, int64_t r_stride,
              float a, float b, int32_t dim, void *stream);
 
-/* y[i, :dim] = a * y[i, :dim] + b * r[i, :dim]  for i < n_rows (epilogue after an exchange). */
-int lgc_axpby(float *y, int64_t y_stride, const float *r, int64_t r_stride,
-              float a, float b, int64_t n_rows, int32_t dim, void *stream);
-
 /* y[i, :dim] = sum_t coef[t] * src[t][i, :dim]  for i < n_rows, terms added in index order, each product
  * rounded before its add -- the order of the reference's running layer sum `out = out + x * alpha`
  * (src/lightgcn.py:93,97).  `src`, `src_stride`, `coef` are HOST arrays of n_terms (1..LGC_MAX_TERMS) entries;

@@ -36,7 +36,7 @@ def counters(d, sub):
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
 
 
-HOP_KERNELS = ("k_spmm_rows", "k_spmm_chunks", "k_spmm_combine", "k_lincomb")
+HOP_KERNELS = ("k_spmm_hop", "k_spmm_rows", "k_spmm_chunks", "k_spmm_combine", "k_lincomb")
 
 
 def main(d, n_hops=0):

@@ -35,7 +35,7 @@ class CpuOps:
         op = CpuOp(rowptr, edge_index[0][order], val[order], 0, num_nodes)
         return CpuGraph(op, val if keep_edge_values else None)
 
-    def restrict(self, op, row_begin, row_end):
+    def restrict(self, op, row_begin, row_end, short_max=None):
         return CpuOp(op.rowptr, op.cols, op.vals, row_begin, row_end)
 
     def apply(self, op, x, out, a, r, b):
@@ -47,8 +47,3 @@ class CpuOps:
         if r is not None:
             res = res + b * r[lo:hi]
         out[lo:hi] = res
-
-    def axpby(self, y, r, a, b):
-        y.mul_(a)
-        if r is not None:
-            y.add_(b * r)
