@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--config", choices=["cosmetics", "small"], default="cosmetics")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = auto)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
+                    "to rehearse the N > 1 path with several ranks on ONE GPU)")
     return ap.parse_args()
 
 
@@ -77,11 +79,14 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         args.gpus = world
-    dev = torch.device(f"cuda:{local_rank}")
+    dev = torch.device(f"cuda:{local_rank % max(torch.cuda.device_count(), 1)}")
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     import gnn_ecommerce_amd as lg
     from gnn_ecommerce_amd import propagate, synth
@@ -105,7 +110,8 @@ def main():
         from gnn_ecommerce_amd.partition import PartitionedPropagator
         pp = PartitionedPropagator(ei, ew, graph.n_users, graph.n_items, rank, world)
         step = lambda: pp.propagate_sum(x0, alphas)
-        parallelism = f"user-range x{world}, items replicated, all-reduce [n_items,D]/hop"
+        parallelism = (f"user-range x{world}, items replicated, all-reduce [n_items,D]/hop over {args.backend}"
+                       + ("" if args.backend == "nccl" else " (rehearsal, not RCCL)"))
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t0
     del ei, ew
