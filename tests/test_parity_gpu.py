@@ -419,6 +419,39 @@ def test_cpu_tensors_are_refused():
         model.get_embedding(torch.zeros((2, 3), dtype=torch.long), None)
 
 
+def test_full_scale_against_the_oracle(device):
+    """BASELINE.json configs[1] at full size, directly against the reference-semantics CPU path
+    (about 10 s of host time): whole tensor, worst row, the hub rows, and accuracy vs an fp64 evaluation."""
+    g = synth.make_bipartite(**synth.CONFIG_COSMETICS, seed=0)
+    ei, ew = g.coo()
+    n, dim, layers = g.num_nodes, 64, 3
+    w0 = synth.xavier_table(n, dim, 0)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    with torch.no_grad():
+        want = oracle.get_embedding(w0, oracle.default_alpha(layers), ei, ew, layers)
+    model = lg.LightGCN(n, dim, layers)
+    model.load_state_dict({"alpha": model.alpha, "embedding.weight": w0})
+    model.to(device)
+    with torch.no_grad():
+        emb = model.get_embedding(ei.to(device), ew.to(device)).cpu()
+    fro, worst = rel_fro(emb, want), worst_row_rel(emb, want)
+    deg = torch.bincount(ei[1], minlength=n)
+    hubs = torch.topk(deg, 20).indices
+    hub_err = worst_row_rel(emb[hubs], want[hubs])
+    print(f"full size: fro {fro:.2e}  worst row {worst:.2e}  20 hub rows (deg <= {int(deg.max())}) {hub_err:.2e}")
+    assert fro <= TOL and worst <= TOL and hub_err <= TOL
+    # a sample of rows against fp64 arithmetic on the same fp32 edge values: not less accurate than the reference
+    val = oracle.gcn_norm(ei, ew, n).double()
+    x = w0.double()
+    out64 = 0.25 * x
+    src, dst = ei[0], ei[1]
+    for _ in range(layers):
+        x = torch.zeros_like(x).index_add_(0, dst, val.view(-1, 1) * x[src])
+        out64 = out64 + 0.25 * x
+    rows = torch.cat([hubs, torch.arange(0, n, 9973)])
+    assert worst_row_rel(emb[rows], out64[rows]) <= 2 * max(worst_row_rel(want[rows], out64[rows]), 1e-7)
+
+
 def test_full_scale_properties(device):
     """BASELINE.json configs[1] size: properties that do not need the (9 s/layer) CPU oracle --
     linearity, adjointness <A^k x, y> = <x, (A^T)^k y>, and agreement of two different plans."""
