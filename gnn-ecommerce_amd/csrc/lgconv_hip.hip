@@ -238,13 +238,10 @@ __device__ __forceinline__ void store_row(float *p, const Acc<VEC> &o) {
 // XCD's 4 MiB L2, where 0.42 GB of output per layer evicts the gathered rows (the only data with reuse);
 // an sc1 (write-through) store drops the line from L2 instead (MI355X_MICROARCH.md, table of store
 // flavours).  Needs a buffer descriptor: 32-bit byte offsets, so only for tables below 4 GiB (wt_store).
-#ifndef LGC_WT
-#define LGC_WT 1
-#endif
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 template <int VEC>
 __device__ __forceinline__ void store_out(const SpmmArgs &p, int64_t row, int c0, const Acc<VEC> &o) {
-    if constexpr (VEC == 4 && LGC_WT) {
+    if constexpr (VEC == 4) {
         if (p.wt_store) {
             auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.y, 0, 0xFFFFFFFFu, 0x00020000);
             f4 t = {o.v[0], o.v[1], o.v[2], o.v[3]};
@@ -405,9 +402,6 @@ __device__ __forceinline__ void rows_slab_body(const SpmmArgs &p, int64_t block)
     finish_row<VEC>(p, row, c0, acc, rv);
 }
 
-#ifndef LGC_PIPE
-#define LGC_PIPE 1
-#endif
 // Long rows: one wavefront per chunk.  Lane group g takes entries begin+g, begin+g+G, ...;
 // the G group sums are then added in group order by lane group 0.
 template <int VEC>
@@ -429,7 +423,6 @@ __device__ __forceinline__ void chunks_body(const SpmmArgs &p, const lgc_chunk *
         const float *xb = p.x + c0;
         const lgc_entry *__restrict__ ent = p.entries;
         int32_t k = ch.begin + g;
-#if LGC_PIPE
         // software pipeline: the entries of step t+1 are requested before the gathers of step t are
         // consumed, so a step costs one memory round trip (the gathers) instead of two
         const int32_t step = 4 * groups;
@@ -450,19 +443,6 @@ __device__ __forceinline__ void chunks_body(const SpmmArgs &p, const lgc_chunk *
             mul_add<VEC>(acc, e2.val, x2);
             mul_add<VEC>(acc, e3.val, x3);
         }
-#else
-        for (; k + 3 * groups < ch.end; k += 4 * groups) {
-            lgc_entry e0 = ent[k], e1 = ent[k + groups], e2 = ent[k + 2 * groups], e3 = ent[k + 3 * groups];
-            Acc<VEC> x0 = load_row<VEC>(xb + (int64_t)e0.col * p.x_stride);
-            Acc<VEC> x1 = load_row<VEC>(xb + (int64_t)e1.col * p.x_stride);
-            Acc<VEC> x2 = load_row<VEC>(xb + (int64_t)e2.col * p.x_stride);
-            Acc<VEC> x3 = load_row<VEC>(xb + (int64_t)e3.col * p.x_stride);
-            mul_add<VEC>(acc, e0.val, x0);
-            mul_add<VEC>(acc, e1.val, x1);
-            mul_add<VEC>(acc, e2.val, x2);
-            mul_add<VEC>(acc, e3.val, x3);
-        }
-#endif
         for (; k < ch.end; k += groups) {
             lgc_entry e0 = ent[k];
             Acc<VEC> x0 = load_row<VEC>(xb + (int64_t)e0.col * p.x_stride);
@@ -727,7 +707,7 @@ int lgc_build_csr(const int64_t *edge_index, const float *edge_weight, int64_t n
 
 int lgc_build_slab(const int32_t *rowptr, const lgc_entry *entries, int64_t n_rows, int32_t width, lgc_entry *slab,
                    void *stream_) {
-    if (!rowptr || !slab || n_rows < 0 || (width != 4 && width != 8 && width != 16)) return LGC_E_INVAL;
+    if (!rowptr || !slab || n_rows < 0 || width != 8) return LGC_E_INVAL;
     if (n_rows == 0) return 0;
     hipLaunchKernelGGL(k_build_slab, dim3(ceil_div(n_rows * width, kBlock)), dim3(kBlock), 0, as_stream(stream_),
                        rowptr, entries, n_rows, width, slab);
@@ -750,7 +730,7 @@ int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin,
     // allocations) are the fast case, nothing else is rejected
     if (!aligned_to(x, 4) || !aligned_to(y, 4) || (r && !aligned_to(r, 4))) return LGC_E_ALIGN;
     hipStream_t stream = as_stream(stream_);
-    if (slab && slab_width != 4 && slab_width != 8 && slab_width != 16) return LGC_E_INVAL;
+    if (slab && slab_width != 8) return LGC_E_INVAL;
     const bool use_slab = slab != nullptr && cfg.vec == 4 && cfg.lpr >= slab_width;
     SpmmArgs p{rowptr, entries, x, y, r, x_stride, y_stride, r_stride, a, b, dim, cfg.lpr, row_begin, row_end,
                short_max, use_slab ? slab : nullptr, use_slab ? slab_width : 0, 0};
@@ -766,12 +746,8 @@ int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin,
         const dim3 grid(row_blocks + chunk_blocks);
         if (grid.x > 0) {
             if constexpr (V == 4) {
-                if (p.slab_width == 4)
-                    hipLaunchKernelGGL((k_spmm_hop<4, 4>), grid, dim3(kBlock), 0, stream, p, chunks, n_chunks, partials, chunk_blocks);
-                else if (p.slab_width == 8)
+                if (p.slab_width == 8)
                     hipLaunchKernelGGL((k_spmm_hop<4, 8>), grid, dim3(kBlock), 0, stream, p, chunks, n_chunks, partials, chunk_blocks);
-                else if (p.slab_width == 16)
-                    hipLaunchKernelGGL((k_spmm_hop<4, 16>), grid, dim3(kBlock), 0, stream, p, chunks, n_chunks, partials, chunk_blocks);
                 else
                     hipLaunchKernelGGL((k_spmm_hop<4, 0>), grid, dim3(kBlock), 0, stream, p, chunks, n_chunks, partials, chunk_blocks);
             } else {

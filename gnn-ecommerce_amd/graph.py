@@ -28,7 +28,7 @@ from . import _native
 # are cut into chunks of about CHUNK_LEN entries, one wavefront each.
 SHORT_MAX = int(os.environ.get("LGCN_SHORT_MAX", "32"))
 CHUNK_LEN = int(os.environ.get("LGCN_CHUNK_LEN", "256"))
-# Width of the fixed slab of row heads the short-row kernel reads (0 = off): 4, 8 or 16 entries.
+# Width of the fixed slab of row heads the short-row kernel reads: 8 entries (0 = off).
 SLAB_WIDTH = int(os.environ.get("LGCN_SLAB_WIDTH", "8"))
 
 

@@ -109,7 +109,8 @@ int lgc_build_csr(const int64_t *edge_index, const float *edge_weight,
 /* Fixed-width slab of the CSR's row heads: slab[row * width + j] = entries[rowptr[row] + j] for
  * j < min(degree, width), {col = -1, val = 0} beyond.  With it lgc_spmm fetches a short row's entries in
  * the same memory round trip as its row pointer (the address depends on the row id only), which is what
- * bounds the short-row kernel.  width: 4, 8 or 16.  slab: lgc_entry [n_rows * width]. */
+ * bounds the short-row kernel.  width: 8 (W=4: 775, W=16: 879 vs 737 us per hop).
+ * slab: lgc_entry [n_rows * width]. */
 int lgc_build_slab(const int32_t *rowptr, const lgc_entry *entries, int64_t n_rows, int32_t width,
                    lgc_entry *slab, void *stream);
 
