@@ -23,6 +23,7 @@ class CpuOp:
 class CpuGraph:
     forward_op: CpuOp
     edge_values: Optional[torch.Tensor]
+    transpose_op: Optional[CpuOp] = None
 
 
 class CpuOps:
@@ -33,7 +34,11 @@ class CpuOps:
         counts = torch.bincount(edge_index[1], minlength=num_nodes)
         rowptr = torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(0)])
         op = CpuOp(rowptr, edge_index[0][order], val[order], 0, num_nodes)
-        return CpuGraph(op, val if keep_edge_values else None)
+        order_t = torch.sort(edge_index[0], stable=True).indices           # rows = sources, same per-edge values
+        counts_t = torch.bincount(edge_index[0], minlength=num_nodes)
+        rowptr_t = torch.cat([torch.zeros(1, dtype=torch.long), counts_t.cumsum(0)])
+        op_t = CpuOp(rowptr_t, edge_index[1][order_t], val[order_t], 0, num_nodes)
+        return CpuGraph(op, val if keep_edge_values else None, op_t)
 
     def restrict(self, op, row_begin, row_end, short_max=None):
         return CpuOp(op.rowptr, op.cols, op.vals, row_begin, row_end)

@@ -15,17 +15,19 @@ from conftest import ROOT
 
 
 def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+    """A fresh rendezvous FILE (no TCP port to race for); the name is kept for the call sites."""
+    import tempfile
+    fd, path = tempfile.mkstemp(prefix="lgcn_rdzv_")
+    os.close(fd)
+    os.unlink(path)
+    return path
 
 
 def _worker(rank, world, port, layers, dim, alpha_kind, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(2)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     try:
         from cpu_ops import CpuOps
         from oracle import lightgcn_oracle as oracle
@@ -77,3 +79,74 @@ def test_partitioned_propagate_matches_single_process_oracle(world, layers, dim,
         assert r["ranges"] == ranges
         assert r["own_users"] <= 1e-5 and r["items"] <= 1e-5 and r["gathered"] <= 1e-5, (rank, r)
         assert r["items_identical"]
+
+
+def _train_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
+    try:
+        from cpu_ops import CpuOps
+        from oracle import lightgcn_oracle as oracle
+        from gnn_ecommerce_amd import synth
+        from gnn_ecommerce_amd.partition import PartitionedPropagator, partitioned_bpr_loss
+        g = synth.make_bipartite(400, 70, 3000, seed=11)
+        ei, ew = g.coo()
+        n, dim, layers, decay, batch = g.num_nodes, 32, 3, 1e-4, 64
+        alpha = oracle.default_alpha(layers)
+        w0 = synth.xavier_table(n, dim, 4)
+        gen = torch.Generator().manual_seed(5)
+        users = torch.randperm(g.n_users, generator=gen)[:batch]
+        if world == 3:
+            users = users[users < 150]            # leave the last rank without a single own triple
+            batch = users.numel()
+        pos = torch.randint(0, g.n_items, (batch,), generator=gen) + g.n_users
+        neg = torch.randint(0, g.n_items, (batch,), generator=gen) + g.n_users
+        # single-process reference (src/train_lightgcn.py:137-146 through the oracle)
+        wr = w0.clone().requires_grad_(True)
+        _, bpr, reg, loss = oracle.train_step_loss(wr, alpha, ei, ew, users, pos, neg, layers, decay)
+        loss.backward()
+        # partitioned
+        pp = PartitionedPropagator(ei, ew, g.n_users, g.n_items, rank, world, ops=CpuOps())
+        w = w0.clone().requires_grad_(True)
+        local, gbpr, greg = partitioned_bpr_loss(pp, w, alpha.tolist(), users, pos, neg, decay,
+                                                 pair_scores=oracle.pair_scores)
+        local.backward()
+        lo, hi = pp.ranges[rank]
+
+        def rel(a, b):
+            return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+        foreign = torch.ones(g.n_users, dtype=torch.bool)
+        foreign[lo:hi] = False
+        q.put((rank, {"bpr": abs(gbpr.item() - bpr.item()) / abs(bpr.item()),
+                      "reg": abs(greg.item() - reg.item()) / abs(reg.item()),
+                      "grad_own_users": rel(w.grad[lo:hi], wr.grad[lo:hi]) if hi > lo else 0.0,
+                      "grad_items": rel(w.grad[g.n_users:], wr.grad[g.n_users:]),
+                      "grad_foreign_zero": bool((w.grad[:g.n_users][foreign] == 0).all()),
+                      "own_triples": int(((users >= lo) & (users < hi)).sum())}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_partitioned_training_step_matches_single_process_gradients(world):
+    """Row (e) of the hot-path contract end to end: forward, pair routing to the user's owner, BPR + regulariser,
+    backward on A^T with the item-gradient all-reduce -- against the oracle's autograd on one process."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if world == 3:
+        assert results[2]["own_triples"] == 0           # the collective path without any own pair
+    for rank, r in results.items():
+        assert r["bpr"] <= 1e-5 and r["reg"] <= 1e-5, (rank, r)
+        assert r["grad_own_users"] <= 2e-5 and r["grad_items"] <= 2e-5, (rank, r)
+        assert r["grad_foreign_zero"], (rank, r)

@@ -66,3 +66,65 @@ def test_two_ranks_one_gpu_match_single_gpu(device):
     for rank, r in results.items():
         assert r["own"] <= 1e-5 and r["items"] <= 1e-5 and r["full"] <= 1e-5 and r["worst_row"] <= 1e-5, (rank, r)
         assert 0.45 <= r["share"] <= 0.55
+
+
+def _train_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gnn_ecommerce_amd as lg
+        from gnn_ecommerce_amd import synth
+        from gnn_ecommerce_amd.partition import PartitionedPropagator, partitioned_bpr_loss
+        dev = torch.device("cuda:0")
+        g = synth.make_bipartite(20000, 1500, 150000, seed=3)
+        ei, ew = g.coo(dev)
+        n, dim, layers, decay, batch = g.num_nodes, 64, 3, 1e-4, 1024
+        w0 = synth.xavier_table(n, dim, 2, dev)
+        gen = torch.Generator().manual_seed(9)
+        users = torch.randperm(g.n_users, generator=gen)[:batch].to(dev)
+        pos = (torch.randint(0, g.n_items, (batch,), generator=gen) + g.n_users).to(dev)
+        neg = (torch.randint(0, g.n_items, (batch,), generator=gen) + g.n_users).to(dev)
+        # single-GPU model, the step of src/train_lightgcn.py:137-146
+        model = lg.LightGCN(n, dim, layers)
+        model.load_state_dict({"alpha": model.alpha, "embedding.weight": w0.cpu()})
+        model.to(dev)
+        labels = torch.stack((torch.cat([users, users]), torch.cat([pos, neg])))
+        out = model(ei, labels, ew)
+        bpr = model.recommendation_loss(out[:batch], out[batch:], 0) * batch
+        w = model.embedding.weight
+        reg = 0.5 * (w[users].norm().pow(2) + w[pos].norm().pow(2) + w[neg].norm().pow(2)) / batch * decay
+        (bpr + reg).backward()
+        ref_grad = w.grad
+        # partitioned, real HipOps
+        pp = PartitionedPropagator(ei, ew, g.n_users, g.n_items, rank, world)
+        wp = w0.clone().requires_grad_(True)
+        local, gbpr, greg = partitioned_bpr_loss(pp, wp, [0.25] * 4, users, pos, neg, decay)
+        local.backward()
+        torch.cuda.synchronize()
+        lo, hi = pp.ranges[rank]
+
+        def rel(a, b):
+            return ((a.double() - b.double()).norm() / b.double().norm()).item()
+
+        q.put((rank, {"bpr": abs(gbpr.item() - bpr.item()) / abs(bpr.item()),
+                      "reg": abs(greg.item() - reg.item()) / abs(reg.item()),
+                      "own": rel(wp.grad[lo:hi], ref_grad[lo:hi]), "items": rel(wp.grad[g.n_users:], ref_grad[g.n_users:])}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_training_step_matches_single_gpu(device):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, r in results.items():
+        assert r["bpr"] <= 1e-5 and r["reg"] <= 1e-5 and r["own"] <= 2e-5 and r["items"] <= 2e-5, (rank, r)
