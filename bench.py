@@ -26,6 +26,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# dmabuf IPC for RCCL / multi-process GPU work on this pool: must be in the environment before HIP initialises
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch
 import torch.distributed as dist
@@ -82,7 +84,6 @@ def main():
     dev = torch.device(f"cuda:{local_rank % max(torch.cuda.device_count(), 1)}")
     torch.cuda.set_device(dev)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
