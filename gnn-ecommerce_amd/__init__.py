@@ -12,6 +12,7 @@ from .graph import PropGraph, build_row_plan, clear_cache, get_graph
 from .lgconv import LGConv
 from .lightgcn import BPRLoss, LightGCN
 from .propagate import check_index_status, hop, pair_dot, propagate_sum
+from .sampler import TripleSampler
 
 __all__ = ["LightGCN", "BPRLoss", "LGConv", "PropGraph", "get_graph", "clear_cache", "build_row_plan",
-           "propagate_sum", "hop", "pair_dot", "check_index_status", "_native"]
+           "propagate_sum", "hop", "pair_dot", "check_index_status", "TripleSampler", "_native"]

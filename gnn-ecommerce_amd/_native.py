@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 from typing import Optional
 
 import torch
@@ -17,10 +17,11 @@ import torch
 LIB_NAME = "liblgconv_hip.so"
 # LGCN_LIB_PATH selects another build of the SAME library (A/B kernel experiments); never a fallback.
 LIB_PATH = os.environ.get("LGCN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", LIB_NAME)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # status bits (include/lgconv_hip.h)
 ST_INDEX_OOB = 1
+ST_SAMPLER_EXHAUSTED = 2
 
 # symbol -> (restype, argtypes); tests check every name against the header and the .so
 SIGNATURES = {
@@ -35,6 +36,8 @@ SIGNATURES = {
                          c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float, c_float,
                          c_int32, c_void_p]),
     "lgc_lincomb": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p]),
+    "lgc_sample_triples": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_uint64,
+                                   c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lgc_pair_dot": (c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                              c_void_p, c_void_p]),
     "lgc_pair_dot_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p,

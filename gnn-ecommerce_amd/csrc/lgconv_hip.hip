@@ -605,6 +605,52 @@ __global__ __launch_bounds__(kBlock) void k_pair_dot_bwd(const float *__restrict
 }
 
 // ----------------------------------------------------------------------------------------
+// Mini-batch sampler
+// ----------------------------------------------------------------------------------------
+// splitmix64 finaliser as a counter-based generator: draw(seed, step, sample, attempt) is stateless.
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// unbiased integer in [0, range): 64-bit multiply-high of a 64-bit draw (bias < range / 2^64)
+__device__ __forceinline__ uint64_t bounded(uint64_t r, uint64_t range) { return __umul64hi(r, range); }
+
+__global__ void k_sample_triples(const int64_t *__restrict__ users, int64_t n, const int32_t *__restrict__ pos_ptr,
+                                 const int64_t *__restrict__ pos_items, const int32_t *__restrict__ ign_ptr,
+                                 const int64_t *__restrict__ ign_items, int64_t n_users, int64_t n_items,
+                                 uint64_t seed, uint64_t step, int64_t *__restrict__ pos_out,
+                                 int64_t *__restrict__ neg_out, int32_t *__restrict__ status) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t u = users[i];
+    const uint64_t key = mix64(mix64(seed) ^ mix64(step * 0xD1B54A32D192ED03ull + (uint64_t)i));
+    if (u < 0 || u >= n_users || pos_ptr[u + 1] == pos_ptr[u]) {
+        atomicOr(status, LGC_ST_INDEX_OOB);
+        pos_out[i] = neg_out[i] = n_users;
+        return;
+    }
+    const int32_t pb = pos_ptr[u], pc = pos_ptr[u + 1] - pb;
+    pos_out[i] = pos_items[pb + (int64_t)bounded(mix64(key), (uint64_t)pc)];
+    const int32_t ib = ign_ptr[u], ie = ign_ptr[u + 1];
+    int64_t cand = n_users;
+    bool ok = false;
+    for (int attempt = 0; attempt < 256 && !ok; ++attempt) {
+        cand = n_users + (int64_t)bounded(mix64(key + 0x632BE59BD9B4E019ull * (uint64_t)(attempt + 1)), (uint64_t)n_items);
+        int32_t lo = ib, hi = ie;                       // binary search in the sorted ignore set
+        while (lo < hi) {
+            const int32_t mid = lo + ((hi - lo) >> 1);
+            if (ign_items[mid] < cand) lo = mid + 1; else hi = mid;
+        }
+        ok = !(lo < ie && ign_items[lo] == cand);
+    }
+    if (!ok) atomicOr(status, LGC_ST_SAMPLER_EXHAUSTED);
+    neg_out[i] = cand;
+}
+
+// ----------------------------------------------------------------------------------------
 // dispatch helpers
 // ----------------------------------------------------------------------------------------
 struct DimCfg {
@@ -800,6 +846,17 @@ int lgc_pair_dot_backward(const float *grad_scores, const float *emb, int64_t st
     if (!idx0 || !idx1 || !grad_scores) return LGC_E_INVAL;
     hipLaunchKernelGGL(k_pair_dot_bwd, dim3(ceil_div(n_pairs, kBlock / kWave)), dim3(kBlock), 0, as_stream(stream_),
                        grad_scores, emb, stride, dim, n_nodes, idx0, idx1, n_pairs, grad_emb, status);
+    return (int)hipGetLastError();
+}
+
+int lgc_sample_triples(const int64_t *users, int64_t n, const int32_t *pos_ptr, const int64_t *pos_items,
+                       const int32_t *ign_ptr, const int64_t *ign_items, int64_t n_users, int64_t n_items, uint64_t seed,
+                       uint64_t step, int64_t *pos_out, int64_t *neg_out, int32_t *status, void *stream_) {
+    if (n < 0 || n_users < 0 || n_items < 1 || !status) return LGC_E_INVAL;
+    if (n == 0) return 0;
+    if (!users || !pos_ptr || !pos_items || !ign_ptr || !pos_out || !neg_out) return LGC_E_INVAL;
+    hipLaunchKernelGGL(k_sample_triples, dim3(ceil_div(n, kBlock)), dim3(kBlock), 0, as_stream(stream_), users, n,
+                       pos_ptr, pos_items, ign_ptr, ign_items, n_users, n_items, seed, step, pos_out, neg_out, status);
     return (int)hipGetLastError();
 }
 

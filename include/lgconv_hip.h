@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LGC_ABI_VERSION 3
+#define LGC_ABI_VERSION 4
 
 /* argument errors (negative return values) */
 #define LGC_E_INVAL      (-1)  /* null pointer, negative size, bad flag                    */
@@ -169,6 +169,29 @@ int lgc_pair_dot_backward(const float *grad_scores, const float *emb, int64_t st
                           int32_t dim, int64_t n_nodes,
                           const int64_t *idx0, const int64_t *idx1, int64_t n_pairs,
                           float *grad_emb, int32_t *status, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Mini-batch sampler: for each of the `n` given users one positive and one negative item.
+ * Replaces the per-row Python of batch_loader (src/utils_v2.py:168-181; its caller
+ * src/train_lightgcn.py:132): `p = random.choice(item_id_idx_list)`,
+ * `n = rejection-sample random.randint(0, n_items-1) + n_users until not in ignor_neg_list`.
+ * The users themselves (random.sample without replacement, :174) are drawn by the caller.
+ *
+ *   users       int64 [n]   user ids (rows of the two CSRs below)
+ *   pos_ptr/pos_items   int32 [n_users+1] / int64 [..]  each user's positive item ids (already offset by
+ *                       n_users, duplicates allowed: the choice is uniform over list entries, as upstream)
+ *   ign_ptr/ign_items   int32 [n_users+1] / int64 [..]  each user's ignore set, SORTED ascending per user
+ *   seed, step  the draw is a pure function of (seed, step, position in the batch): counter-based RNG
+ *   pos_out, neg_out    int64 [n]
+ *   status      LGC_ST_INDEX_OOB for a user id outside [0, n_users) or without positives;
+ *               LGC_ST_SAMPLER_EXHAUSTED when 256 draws all hit the ignore set (then neg = last draw)
+ * ------------------------------------------------------------------------------------- */
+#define LGC_ST_SAMPLER_EXHAUSTED 2
+int lgc_sample_triples(const int64_t *users, int64_t n,
+                       const int32_t *pos_ptr, const int64_t *pos_items,
+                       const int32_t *ign_ptr, const int64_t *ign_items,
+                       int64_t n_users, int64_t n_items, uint64_t seed, uint64_t step,
+                       int64_t *pos_out, int64_t *neg_out, int32_t *status, void *stream);
 
 #ifdef __cplusplus
 }

@@ -35,7 +35,7 @@ from torch import Tensor
 __all__ = [
     "gcn_norm", "lgconv", "lgconv_fp64", "OracleLGConv", "get_embedding", "pair_scores",
     "forward", "bpr_loss", "regularization_loss", "batch_pos_neg_edges", "pairs_to_graph",
-    "recommend_topk", "train_step_loss", "default_alpha",
+    "recommend_topk", "train_step_loss", "default_alpha", "batch_loader",
 ]
 
 
@@ -189,3 +189,22 @@ def train_step_loss(weight: Tensor, alpha: Tensor, edge_index: Tensor, edge_weig
     bpr = bpr_loss(scores[:size], scores[size:], weight, 0) * size
     reg = regularization_loss(weight, size, users, pos, neg, decay)
     return scores, bpr, reg, bpr + reg
+
+
+def batch_loader(user_order, pos_lists: dict, ignore_lists: dict, batch_size: int, n_users: int, n_items: int, rng):
+    """src/utils_v2.py:168-181 without the DataFrames; ``rng`` is a ``random.Random`` (upstream uses the module
+    functions, the same Mersenne Twister).  Same call order as upstream, so the same seed gives the same triples
+    (pinned by tests/golden/sampler_ref.npz): users = sample(frame's user column, B); then a positive for every
+    user (``random.choice`` over the list, :178); then a negative for every user (rejection-sampled
+    ``randint(0, n_items - 1) + n_users`` until it is not in the user's ignore list, :169-173,179)."""
+    users = rng.sample(list(user_order), batch_size)
+    pos = [rng.choice(list(pos_lists[u])) for u in users]
+    neg = []
+    for u in users:
+        ign = ignore_lists[u]
+        while True:
+            cand = rng.randint(0, n_items - 1) + n_users
+            if cand not in ign:
+                neg.append(cand)
+                break
+    return torch.LongTensor(users), torch.LongTensor(pos), torch.LongTensor(neg)

@@ -202,6 +202,23 @@ def hub_fixture(ref, utils):
          embedding_sum64=emb.double().sum(0))
 
 
+def sampler_fixture(utils):
+    """batch_loader of the reference itself (src/utils_v2.py:168-181) under random.seed: pins the oracle's
+    restatement of the sampler's semantics AND its RNG call order."""
+    import random
+    from tests_support import sampler_lists
+    n_users, n_items = 60, 25
+    order, pos, ign = sampler_lists(n_users, n_items, seed=1)
+    frame = pd.DataFrame({"user_id_idx": order, "item_id_idx_list": [pos[u] for u in order],
+                          "ignor_neg_list": [ign[u] for u in order]})
+    out = {}
+    for seed in (0, 1, 2):
+        random.seed(seed)
+        triples = [utils.batch_loader(frame, 16, n_users, n_items) for _ in range(3)]        # reference code
+        out[f"seed{seed}"] = torch.stack([torch.stack(t) for t in triples])                 # [3 batches, 3, 16]
+    save("sampler_ref", n_users=n_users, n_items=n_items, lists_seed=1, batch=16, **out)
+
+
 def main():
     ref, utils = import_reference()
     print("reference imported from", ref.__file__)
@@ -210,6 +227,7 @@ def main():
         train_fixture(ref, utils, s, d, k)
     edge_case_fixtures(ref, utils)
     hub_fixture(ref, utils)
+    sampler_fixture(utils)
     meta = {"torch": torch.__version__, "numpy": np.__version__, "pandas": pd.__version__,
             "reference": "happykygo/GNN-eCommerce src/lightgcn.py, src/utils_v2.py (imported, unmodified)",
             "lgconv": "oracle.OracleLGConv (PyG absent: restated, parity unpinned at that boundary)"}

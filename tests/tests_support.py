@@ -33,3 +33,22 @@ def hub_inputs(seed, n_users, n_items, dim):
     ei = torch.stack((torch.cat([u_t, i_t]), torch.cat([i_t, u_t])))
     ew = torch.cat([w_t, w_t])
     return ei, ew, torch.from_numpy(formula_weight(n_users + n_items, dim))
+
+
+def sampler_lists(n_users, n_items, seed):
+    """(user order, positives per user, ignore list per user) in the shape of the reference's train_pos_list_df:
+    users without purchases are absent; item ids are offset by n_users; ignore lists contain the positives."""
+    rng = np.random.default_rng(seed)
+    pos, ign = {}, {}
+    for u in range(n_users):
+        if u % 7 == 3:
+            continue
+        k = int(rng.integers(1, 5))
+        p = (rng.integers(0, n_items, k) + n_users).tolist()
+        extra = (rng.integers(0, n_items, int(rng.integers(0, 12))) + n_users).tolist()
+        pos[u], ign[u] = p, sorted(set(p) | set(extra))
+    ign[5] = [i + n_users for i in range(n_items) if i != 9]        # a single admissible negative
+    pos[5] = [n_users + 1]
+    order = sorted(pos)
+    np.random.default_rng(seed + 100).shuffle(order)
+    return order, pos, ign

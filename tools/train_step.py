@@ -11,6 +11,9 @@ from gnn_ecommerce_amd import synth
 ap = argparse.ArgumentParser()
 ap.add_argument("--dim", type=int, default=64); ap.add_argument("--layers", type=int, default=3)
 ap.add_argument("--steps", type=int, default=10); ap.add_argument("--batch", type=int, default=1024)
+ap.add_argument("--sampler", choices=["uniform", "device", "python"], default="uniform",
+                help="uniform: seeded uniform triples (SURVEY 8d); device: TripleSampler (batch_loader contract on "
+                     "the GPU); python: the oracle restatement of the reference's batch_loader on the host")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 g = synth.make_bipartite(**synth.CONFIG_COSMETICS, seed=0)
@@ -18,7 +21,25 @@ ei, ew = g.coo(dev)
 model = lg.LightGCN(g.num_nodes, args.dim, args.layers).to(dev)
 opt = torch.optim.Adam(model.parameters(), 0.005)
 gen = torch.Generator().manual_seed(0)
+purchase = g.weight == 1.0                      # positives = purchases, as pos_item_list (src/utils_v2.py:64-73)
+pu, pi = g.user[purchase], g.item[purchase] + g.n_users
+if args.sampler == "device":
+    from gnn_ecommerce_amd.sampler import TripleSampler
+    sampler = TripleSampler.from_pairs(g.n_users, g.n_items, pu, pi, pu, pi, dev, seed=0)
+elif args.sampler == "python":
+    import random
+    from oracle import lightgcn_oracle as oracle
+    import numpy as np
+    order = np.argsort(pu, kind="stable"); su, si = pu[order], pi[order]
+    cuts = np.flatnonzero(np.diff(su)) + 1
+    lists = dict(zip(su[np.concatenate([[0], cuts])].tolist(), [a.tolist() for a in np.split(si, cuts)]))
+    user_order, rng = list(lists), random.Random(0)
 def batch():
+    if args.sampler == "device":
+        return sampler.sample(args.batch)
+    if args.sampler == "python":
+        u, p, n = oracle.batch_loader(user_order, lists, lists, args.batch, g.n_users, g.n_items, rng)
+        return u.to(dev), p.to(dev), n.to(dev)
     u = torch.randint(0, g.n_users, (args.batch,), generator=gen)
     p = torch.randint(0, g.n_items, (args.batch,), generator=gen) + g.n_users
     n = torch.randint(0, g.n_items, (args.batch,), generator=gen) + g.n_users
@@ -41,4 +62,4 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(args.steps): vals = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / args.steps
 print(json.dumps({"metric": "training steps/s (fwd+bwd+Adam, B=%d)" % args.batch, "value": 1 / dt, "ms_per_step": dt * 1e3,
-                  "dim": args.dim, "layers": args.layers, "loss": vals[2]}))
+                  "dim": args.dim, "layers": args.layers, "sampler": args.sampler, "loss": vals[2]}))
