@@ -255,8 +255,58 @@ class PropGraph:
     def transpose_op(self) -> Operator:
         """A^T with the SAME per-edge values (exact adjoint, no symmetry assumption)."""
         if self._transpose_op is None:
+            if self._edge_index is None:
+                raise _native.NativeLibraryError("this graph was loaded from a file without its COO: the transposed "
+                                                 "operator (backward pass) needs a graph built from edge_index")
             self._transpose_op = self._build(by_source=True)
         return self._transpose_op
+
+    # -- persistence (SURVEY.md 8f N4): a built graph as a flat safetensors file ------------------
+    def save(self, path: str) -> None:
+        """Write the forward operator (CSR, slab), degrees and metadata; nothing executable in the file.
+        A serving worker can ``PropGraph.load`` it instead of re-reading the CSV, rebuilding the COO
+        (torchserve/lightgcn_handler.py:32-38) and sorting it again."""
+        from safetensors.torch import save_file
+        op = self.forward_op
+        tensors = {"rowptr": op.rowptr, "entries": op.entries, "deg": self.deg, "dis": self.dis}
+        if op.slab is not None:
+            tensors["slab"] = op.slab
+        meta = {"format": "lgcn-graph-1", "num_nodes": str(self.num_nodes), "num_edges": str(self.num_edges),
+                "normalize": str(int(self.normalize)), "slab_width": str(op.slab_width),
+                "split": "" if self.split is None else str(self.split)}
+        save_file({k: v.detach().cpu().contiguous() for k, v in tensors.items()}, path, metadata=meta)
+
+    @classmethod
+    def load(cls, path: str, device, short_max: int = SHORT_MAX, chunk_len: int = CHUNK_LEN) -> "PropGraph":
+        """A graph usable for forward propagation (``get_embedding`` / ``recommendK``).  The COO is not stored,
+        so the transposed operator (training) cannot be derived from a loaded graph."""
+        from safetensors import safe_open
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise _native.NativeLibraryError("graphs are loaded onto a ROCm device only (no CPU fallback)")
+        with safe_open(path, framework="pt", device="cpu") as f:
+            meta = f.metadata() or {}
+            if meta.get("format") != "lgcn-graph-1":
+                raise ValueError(f"{path} is not a saved propagation graph")
+            t = {k: f.get_tensor(k) for k in f.keys()}
+        g = cls.__new__(cls)
+        g.device, g.num_nodes, g.num_edges = device, int(meta["num_nodes"]), int(meta["num_edges"])
+        g.normalize = bool(int(meta["normalize"]))
+        g.short_max, g.chunk_len = short_max, chunk_len
+        g._key_refs = g._edge_index = g._edge_weight = None
+        g.status = torch.zeros(4, dtype=torch.int32, device=device)
+        g.deg, g.dis, g.edge_values = t["deg"].to(device), t["dis"].to(device), None
+        rowptr, entries = t["rowptr"].to(device), t["entries"].to(device)
+        if rowptr.dtype != torch.int32 or rowptr.numel() != g.num_nodes + 1 or entries.shape != (g.num_edges, 2):
+            raise ValueError(f"{path}: inconsistent tensor shapes")
+        slab = t["slab"].to(device) if "slab" in t else None
+        g.forward_op = Operator(g.num_nodes, rowptr, entries,
+                                build_row_plan(rowptr, 0, g.num_nodes, short_max, chunk_len), slab,
+                                int(meta.get("slab_width", "0")) if slab is not None else 0)
+        g._transpose_op = None
+        g.split = int(meta["split"]) if meta.get("split") else None
+        g._halves = {}
+        return g
 
     def nbytes(self) -> int:
         ops = [self.forward_op] + ([self._transpose_op] if self._transpose_op is not None else [])

@@ -401,6 +401,30 @@ def test_recommendk_reuses_propagation_until_weights_change(device):
     assert (np.array(got["top_rlvnt_itm"].tolist()) == want.numpy()).mean() >= 0.95
 
 
+def test_saved_graph_round_trip(device, tmp_path):
+    """SURVEY.md 8f N4 (persisted graph): save -> load gives the same operator, bit for bit, without the COO."""
+    from gnn_ecommerce_amd import propagate
+    g, ei, ew = small_graph(10, 500, 70, 4000)
+    n, dim = g.num_nodes, 64
+    pg = PropGraph(ei.to(device), ew.to(device), n)
+    path = str(tmp_path / "graph.safetensors")
+    pg.save(path)
+    loaded = PropGraph.load(path, device)
+    assert loaded.split == pg.split == g.n_users and loaded.num_edges == pg.num_edges
+    assert torch.equal(loaded.forward_op.rowptr, pg.forward_op.rowptr)
+    assert torch.equal(loaded.forward_op.entries, pg.forward_op.entries)
+    x0 = synth.xavier_table(n, dim, 1, device)
+    alphas = (0.4, 0.3, 0.2, 0.1)
+    assert torch.equal(lg.propagate_sum(x0, loaded, alphas), lg.propagate_sum(x0, pg, alphas))
+    with pytest.raises(lg._native.NativeLibraryError):
+        loaded.transpose_op
+    with pytest.raises(ValueError):
+        bad = str(tmp_path / "bad.safetensors")
+        from safetensors.torch import save_file
+        save_file({"x": torch.zeros(1)}, bad)
+        PropGraph.load(bad, device)
+
+
 def test_graph_cache_tracks_tensor_identity_and_version(device):
     g, ei, ew = small_graph(6)
     ei_d, ew_d = ei.to(device), ew.to(device)
