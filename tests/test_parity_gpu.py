@@ -290,6 +290,19 @@ def test_bipartite_and_horner_evaluations_both_match_the_oracle(device, dim, lay
     assert rel_fro(a[g.n_users:], want[g.n_users:]) <= 2e-6
 
 
+def test_more_layers_than_lincomb_terms_fall_back_to_horner(device):
+    """K = 9 > 7: the bipartite evaluation's item-side sums would need 10 terms (lgc_lincomb takes 8)."""
+    g, ei, ew = small_graph(12, 300, 50, 1800)
+    n, dim, layers = g.num_nodes, 16, 9
+    x0 = synth.xavier_table(n, dim, 6)
+    alpha = torch.linspace(0.3, 0.02, layers + 1)
+    want = oracle.get_embedding(x0, alpha, ei, ew, layers)
+    pg = PropGraph(ei.to(device), ew.to(device), n)
+    assert pg.split is not None
+    got = lg.propagate_sum(x0.to(device), pg, alpha.tolist()).cpu()
+    assert rel_fro(got, want) <= TOL and worst_row_rel(got, want) <= TOL
+
+
 def test_non_bipartite_graph_uses_the_generic_path(device):
     rng = np.random.default_rng(3)
     n, e, dim, layers = 700, 9000, 64, 3
