@@ -514,3 +514,22 @@ def test_full_scale_properties(device):
     # degree: exact against a host-side sequential fp32 scatter on the same edge order
     deg = torch.zeros(n).scatter_add_(0, ei[1].cpu(), ew.cpu())
     assert torch.equal(pg.deg.cpu(), deg)
+
+
+def test_end_to_end_caller_loop_learns(device):
+    """The reference's whole caller loop (sampler -> step -> recommendK -> MARK_MAPK, tools/train_demo.py) on
+    synthetic latent-factor data: the BPR loss falls and recall@20 on held-out purchases beats chance by far."""
+    import importlib.util, os, sys
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("train_demo", os.path.join(ROOT, "tools", "train_demo.py"))
+    demo = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(demo)
+    argv = sys.argv
+    sys.argv = ["train_demo", "--users", "6000", "--items", "800", "--epochs", "3"]
+    try:
+        log = demo.main()
+    finally:
+        sys.argv = argv
+    assert log[-1]["bpr"] < log[0]["bpr"] < 0.70
+    chance = 20 / 800
+    assert log[-1]["R@20"] > 4 * chance and log[-1]["R@20"] >= log[0]["R@20"] - 0.02

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""The reference's caller loop end to end on the drop-in (counterpart of TrainLightGCN.train / .test,
+src/train_lightgcn.py:79-162): per epoch n_batch mini-batches (sampler -> labels -> forward -> bpr*size + reg ->
+backward -> Adam), then recommendK + MARK_MAPK on held-out purchases.  Data are synthetic with latent structure
+(users and items drawn around a few taste centres) so that there is something to learn.
+
+    python tools/train_demo.py [--users 20000 --items 2000 --epochs 3 --dim 64 --layers 3]
+"""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import pandas as pd
+import torch
+import gnn_ecommerce_amd as lg
+
+
+def latent_interactions(n_users, n_items, per_user, seed):
+    rng = np.random.default_rng(seed)
+    k, d = 12, 8
+    centres = rng.normal(size=(k, d))
+    uz = centres[rng.integers(k, size=n_users)] + 0.3 * rng.normal(size=(n_users, d))
+    iz = centres[rng.integers(k, size=n_items)] + 0.3 * rng.normal(size=(n_items, d))
+    users, items = [], []
+    for lo in range(0, n_users, 4096):
+        s = uz[lo:lo + 4096] @ iz.T + 1.5 * rng.gumbel(size=(min(4096, n_users - lo), n_items))
+        top = np.argpartition(-s, per_user, axis=1)[:, :per_user]
+        users.append(np.repeat(np.arange(lo, lo + top.shape[0]), per_user)); items.append(top.ravel())
+    return np.concatenate(users), np.concatenate(items)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--users", type=int, default=20000); ap.add_argument("--items", type=int, default=2000)
+    ap.add_argument("--per-user", type=int, default=12); ap.add_argument("--epochs", type=int, default=3)
+    ap.add_argument("--dim", type=int, default=64); ap.add_argument("--layers", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024); ap.add_argument("--k", type=int, default=20)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    u, i = latent_interactions(args.users, args.items, args.per_user, 0)
+    rng = np.random.default_rng(1)
+    held = rng.random(len(u)) < 0.15                                  # held-out purchases per user
+    n_users, n_items = args.users, args.items
+    train = pd.DataFrame({"user_id_idx": u[~held], "item_id_idx": i[~held] + n_users, "weight": 1.0})
+    test = pd.DataFrame({"user_id_idx": u[held], "item_id_idx": i[held]})
+    test_pos = test.groupby("user_id_idx")["item_id_idx"].apply(list).reset_index()
+    test_pos.columns = ["user_id_idx", "item_id_idx_list"]
+    test_pos = test_pos.iloc[:2000]
+    # graph exactly as df_to_graph lays it out (src/utils_v2.py:146-165)
+    u_t, i_t = torch.LongTensor(train["user_id_idx"].values), torch.LongTensor(train["item_id_idx"].values)
+    edge_index = torch.stack((torch.cat([u_t, i_t]), torch.cat([i_t, u_t]))).to(dev)
+    w_t = torch.FloatTensor(train["weight"].values)
+    edge_weight = torch.cat([w_t, w_t]).to(dev)
+    sampler = lg.TripleSampler.from_pairs(n_users, n_items, train["user_id_idx"].values, train["item_id_idx"].values,
+                                          train["user_id_idx"].values, train["item_id_idx"].values, dev, seed=0)
+    seen = torch.zeros(len(test_pos), n_items)
+    tr = train[train["user_id_idx"].isin(test_pos["user_id_idx"])]
+    row_of = {uu: r for r, uu in enumerate(test_pos["user_id_idx"])}
+    seen[[row_of[uu] for uu in tr["user_id_idx"]], (tr["item_id_idx"] - n_users).values] = 1.0
+
+    model = lg.LightGCN(n_users + n_items, args.dim, args.layers).to(dev)
+    opt = torch.optim.Adam(model.parameters(), 0.005)
+    n_batch = max(1, len(train) // (args.batch * 4))
+    log = []
+    for epoch in range(args.epochs):
+        model.train(); t0 = time.perf_counter(); losses = []
+        for _ in range(n_batch):                                        # train_lightgcn.py:129-151
+            opt.zero_grad()
+            users, pos, neg = sampler.sample(args.batch)
+            labels = torch.stack((torch.cat([users, users]), torch.cat([pos, neg])))
+            out = model(edge_index, labels, edge_weight)
+            size = len(users)
+            bpr = model.recommendation_loss(out[:size], out[size:], 0) * size
+            w = model.embedding.weight
+            reg = 0.5 * (w[users].norm().pow(2) + w[pos].norm().pow(2) + w[neg].norm().pow(2)) / size * 1e-4
+            (bpr + reg).backward()
+            opt.step()
+            losses.append(bpr.item())
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        model.eval()
+        with torch.no_grad():                                           # train_lightgcn.py:155-162
+            top = model.recommendK(edge_index, edge_weight, n_users, n_items, seen, list(test_pos["user_id_idx"]), args.k)
+            precision, recall, _ = model.MARK_MAPK(test_pos, top, args.k)
+        log.append({"epoch": epoch, "bpr": float(np.mean(losses)), f"P@{args.k}": float(precision),
+                    f"R@{args.k}": float(recall), "batches": n_batch, "s": round(dt, 2)})
+        print(json.dumps(log[-1]), flush=True)
+    sampler.check(); lg.check_index_status()
+    return log
+
+
+if __name__ == "__main__":
+    main()
