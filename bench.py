@@ -86,6 +86,23 @@ def cpu_baseline(graph, layers, dim, threads=0):
     return out
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes through
+    torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1), relay their output -- rank 0 prints the
+    JSON line -- and hand back their exit code.  The parent never initialises HIP and never exec()s."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -93,7 +110,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            sys.exit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+            sys.exit(self_launch(args.gpus))   # plain `python bench.py --gpus N`: nothing has touched the GPU yet
         args.gpus = world
     dev = torch.device(f"cuda:{local_rank % max(torch.cuda.device_count(), 1)}")
     torch.cuda.set_device(dev)

@@ -53,3 +53,15 @@ def test_two_rank_launch_as_the_driver_does_it(device):
     d = check_line(out.stdout, 2, 2, 1)
     assert "cpu_baseline" not in d                                    # rank 0 at N = 1 only
     assert d["roofline"]["launches_timed"] == 2 * 3
+
+
+def test_plain_python_launch_with_gpus_2_starts_its_own_ranks(device):
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE (how the driver ran BENCH): bench.py starts
+    the ranks itself as child processes and relays rank 0's line with the children's exit code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--config", "small", "--backend", "gloo"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = check_line(out.stdout, 2, 2, 1)
+    assert "cpu_baseline" not in d

@@ -21,15 +21,25 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _init(rank, world, port, backend):
+    """gloo: every rank on cuda:0.  nccl (= RCCL): one rank per GPU, as the driver launches bench.py."""
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device(f"cuda:{rank}" if backend == "nccl" else "cuda:0")
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return dev
+
+
+def _worker(rank, world, port, q, backend="gloo"):
+    dev = _init(rank, world, port, backend)
     try:
         import gnn_ecommerce_amd as lg
         from gnn_ecommerce_amd import synth
         from gnn_ecommerce_amd.partition import PartitionedPropagator
-        dev = torch.device("cuda:0")
         g = synth.make_bipartite(20000, 1500, 150000, seed=3)
         ei, ew = g.coo(dev)
         n, dim, alphas = g.num_nodes, 64, (0.4, 0.3, 0.2, 0.1)
@@ -46,37 +56,43 @@ def _worker(rank, world, port, q):
         lo, hi = pp.ranges[rank]
         q.put((rank, {"own": rel(out[lo:hi], single[lo:hi]), "items": rel(out[g.n_users:], single[g.n_users:]),
                       "full": rel(full, single), "worst_row": ((full - single).norm(dim=1) / single.norm(dim=1)).max().item(),
-                      "share": pp.local_nnz / g.nnz}))
+                      "share": pp.local_nnz / g.nnz, "world": dist.get_world_size(), "backend": dist.get_backend()}))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_one_gpu_match_single_gpu(device):
-    world = 2
+def run_ranks(target, world, backend="gloo"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=target, args=(r, world, port, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
-    results = dict(q.get(timeout=300) for _ in range(world))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        results = dict(q.get(timeout=300) for _ in range(world))
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(results) == list(range(world))
+    return results
+
+
+def test_two_ranks_one_gpu_match_single_gpu(device):
+    results = run_ranks(_worker, 2)
     for rank, r in results.items():
         assert r["own"] <= 1e-5 and r["items"] <= 1e-5 and r["full"] <= 1e-5 and r["worst_row"] <= 1e-5, (rank, r)
         assert 0.45 <= r["share"] <= 0.55
 
 
-def _train_worker(rank, world, port, q):
-    sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _train_worker(rank, world, port, q, backend="gloo"):
+    dev = _init(rank, world, port, backend)
     try:
         import gnn_ecommerce_amd as lg
         from gnn_ecommerce_amd import synth
         from gnn_ecommerce_amd.partition import PartitionedPropagator, partitioned_bpr_loss
-        dev = torch.device("cuda:0")
         g = synth.make_bipartite(20000, 1500, 150000, seed=3)
         ei, ew = g.coo(dev)
         n, dim, layers, decay, batch = g.num_nodes, 64, 3, 1e-4, 1024
@@ -109,22 +125,13 @@ def _train_worker(rank, world, port, q):
 
         q.put((rank, {"bpr": abs(gbpr.item() - bpr.item()) / abs(bpr.item()),
                       "reg": abs(greg.item() - reg.item()) / abs(reg.item()),
-                      "own": rel(wp.grad[lo:hi], ref_grad[lo:hi]), "items": rel(wp.grad[g.n_users:], ref_grad[g.n_users:])}))
+                      "own": rel(wp.grad[lo:hi], ref_grad[lo:hi]), "items": rel(wp.grad[g.n_users:], ref_grad[g.n_users:]),
+                      "world": dist.get_world_size(), "backend": dist.get_backend()}))
     finally:
         dist.destroy_process_group()
 
 
 def test_two_ranks_training_step_matches_single_gpu(device):
-    world = 2
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    results = dict(q.get(timeout=300) for _ in range(world))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    results = run_ranks(_train_worker, 2)
     for rank, r in results.items():
-        assert r["bpr"] <= 1e-5 and r["reg"] <= 1e-5 and r["own"] <= 2e-5 and r["items"] <= 2e-5, (rank, r)
+        assert r["bpr"] <= 1e-5 and r["reg"] <= 1e-5 and r["own"] <= 1e-5 and r["items"] <= 1e-5, (rank, r)

@@ -52,3 +52,22 @@ def sampler_lists(n_users, n_items, seed):
     order = sorted(pos)
     np.random.default_rng(seed + 100).shuffle(order)
     return order, pos, ign
+
+
+def assert_topk_exact_up_to_ties(got, want, ref_masked_scores, rel_gap=1e-6):
+    """Index work is exact: ``got[r, p] == want[r, p]`` everywhere, except where the REFERENCE's own masked
+    scores of the two candidates differ by less than ``rel_gap`` relative to the row's largest |score| (a provable
+    near-tie: an fp32 reordering of the sum can swap them).  ``ref_masked_scores`` is [rows, n_items]."""
+    got, want = np.asarray(got), np.asarray(want)
+    s = np.asarray(ref_masked_scores, dtype=np.float64)
+    assert got.shape == want.shape and s.shape[0] == got.shape[0]
+    bad = np.argwhere(got != want)
+    for r, p in bad:
+        scale = np.abs(s[r]).max()
+        gap = abs(s[r, got[r, p]] - s[r, want[r, p]])
+        assert gap <= rel_gap * scale, (
+            f"row {r} position {p}: got item {got[r, p]} (ref score {s[r, got[r, p]]:.9g}), want {want[r, p]} "
+            f"({s[r, want[r, p]]:.9g}); gap {gap:.3g} is not a tie at scale {scale:.3g}")
+    # whatever was swapped, each row must still hold k distinct items
+    assert all(len(set(row)) == len(row) for row in got.tolist())
+    return len(bad)
