@@ -17,7 +17,7 @@ import torch
 LIB_NAME = "liblgconv_hip.so"
 # LGCN_LIB_PATH selects another build of the SAME library (A/B kernel experiments); never a fallback.
 LIB_PATH = os.environ.get("LGCN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", LIB_NAME)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # status bits (include/lgconv_hip.h)
 ST_INDEX_OOB = 1
@@ -31,10 +31,12 @@ SIGNATURES = {
     "lgc_build_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "lgc_build_csr": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p, c_void_p,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
-    "lgc_build_slab": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "lgc_spmm": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32,
-                         c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float, c_float,
+                         c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float, c_float,
                          c_int32, c_void_p]),
+    "lgc_build_tiles": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
+    "lgc_spmm_tiles": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int64, c_void_p, c_int64,
+                               c_void_p, c_int64, c_void_p, c_int64, c_float, c_float, c_int32, c_void_p]),
     "lgc_lincomb": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p]),
     "lgc_sample_triples": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_uint64,
                                    c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -22,6 +22,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 
 #include "lgconv_hip.h"
 
@@ -188,8 +189,6 @@ struct SpmmArgs {
     float a, b;
     int32_t dim, lpr;  // lanes per row = ceil(dim / VEC)
     int32_t row_begin, row_end, short_max;
-    const lgc_entry *slab;
-    int32_t slab_width;
     int32_t wt_store;  // 1: output rows leave with write-through (sc1) stores, see store_out
 };
 
@@ -239,8 +238,8 @@ __device__ __forceinline__ void store_row(float *p, const Acc<VEC> &o) {
 // an sc1 (write-through) store drops the line from L2 instead (MI355X_MICROARCH.md, table of store
 // flavours).  Needs a buffer descriptor: 32-bit byte offsets, so only for tables below 4 GiB (wt_store).
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-template <int VEC>
-__device__ __forceinline__ void store_out(const SpmmArgs &p, int64_t row, int c0, const Acc<VEC> &o) {
+template <int VEC, class P>
+__device__ __forceinline__ void store_out(const P &p, int64_t row, int c0, const Acc<VEC> &o) {
     if constexpr (VEC == 4) {
         if (p.wt_store) {
             auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.y, 0, 0xFFFFFFFFu, 0x00020000);
@@ -262,8 +261,8 @@ __device__ __forceinline__ void mul_add(Acc<VEC> &acc, float val, const Acc<VEC>
 }
 
 // y = a * acc + b * rv
-template <int VEC>
-__device__ __forceinline__ void finish_row(const SpmmArgs &p, int64_t row, int c0, Acc<VEC> acc, const Acc<VEC> &rv) {
+template <int VEC, class P>
+__device__ __forceinline__ void finish_row(const P &p, int64_t row, int c0, Acc<VEC> acc, const Acc<VEC> &rv) {
     if (p.a != 1.0f) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc.v[i] = __fmul_rn(p.a, acc.v[i]);
@@ -272,7 +271,7 @@ __device__ __forceinline__ void finish_row(const SpmmArgs &p, int64_t row, int c
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc.v[i] = __fadd_rn(acc.v[i], __fmul_rn(p.b, rv.v[i]));
     }
-    store_out<VEC>(p, row, c0, acc);
+    store_out<VEC, P>(p, row, c0, acc);
 }
 
 // Short rows: one lane group per row, entries in order, 4 gathers in flight per group; the epilogue
@@ -314,92 +313,7 @@ __device__ __forceinline__ void rows_body(const SpmmArgs &p, int64_t block) {
         Acc<VEC> x0 = load_row<VEC>(xb + (int64_t)e0.col * p.x_stride);
         mul_add<VEC>(acc, e0.val, x0);
     }
-    finish_row<VEC>(p, row, c0, acc, rv);
-}
-
-__global__ void k_build_slab(const int32_t *__restrict__ rowptr, const lgc_entry *__restrict__ entries,
-                             int64_t n_rows, int32_t width, lgc_entry *__restrict__ slab) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rows * width) return;
-    const int64_t row = i / width;
-    const int32_t j = (int32_t)(i - row * width);
-    const int32_t s = rowptr[row], e = rowptr[row + 1];
-    lgc_entry v;
-    v.col = -1;
-    v.val = 0.0f;
-    if (s + j < e) v = entries[s + j];
-    slab[i] = v;
-}
-
-// Short rows through the slab: lane j < W of a row's group fetches entry j (one coalesced 8*W-byte
-// access per group, issued together with the row pointer and the epilogue row), the group then
-// broadcasts entry after entry with ds_bpermute and gathers.  Round trips per row: slab -> gathers ->
-// store, instead of rowptr -> entries -> gathers -> store.  Entry order is unchanged (bit-exact sums).
-template <int VEC, int W>
-__device__ __forceinline__ void rows_slab_body(const SpmmArgs &p, int64_t block) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int rows_per_wave = kWave / p.lpr;
-    const int g = lane / p.lpr;
-    const int l = lane - g * p.lpr;
-    const int64_t wave = block * (kBlock / kWave) + (threadIdx.x / kWave);
-    const int64_t row = (int64_t)p.row_begin + wave * rows_per_wave + g;
-    const bool valid = g < rows_per_wave && row < p.row_end;
-    const int c0 = lane_column<VEC>(l, p.dim);
-    const int gbase = g * p.lpr;
-
-    lgc_entry mine;
-    mine.col = -1;
-    mine.val = 0.0f;
-    int32_t s = 0, e = 0;
-    Acc<VEC> acc, rv;
-    acc.zero();
-    rv.zero();
-    if (valid) {
-        if (l < W) mine = p.slab[row * W + l];
-        s = p.rowptr[row];
-        e = p.rowptr[row + 1];
-        if (p.r != nullptr) rv = load_row<VEC>(p.r + row * p.r_stride + c0);
-    }
-    const bool mine_row = valid && (e - s) <= p.short_max;   // longer rows belong to the chunk part
-    const int32_t n_head = mine_row ? min(e - s, W) : 0;
-    const float *xb = p.x + c0;
-#pragma unroll
-    for (int j0 = 0; j0 < W; j0 += 4) {
-        int32_t col[4];
-        float val[4];
-        Acc<VEC> xv[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {   // every lane of the wave executes the shuffles
-            col[j] = __shfl(mine.col, gbase + j0 + j);
-            val[j] = __shfl(mine.val, gbase + j0 + j);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (j0 + j < n_head) xv[j] = load_row<VEC>(xb + (int64_t)col[j] * p.x_stride);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (j0 + j < n_head) mul_add<VEC>(acc, val[j], xv[j]);
-    }
-    if (!mine_row) return;
-    const lgc_entry *__restrict__ ent = p.entries;
-    int32_t k = s + W;
-    for (; k + 4 <= e; k += 4) {
-        lgc_entry e0 = ent[k], e1 = ent[k + 1], e2 = ent[k + 2], e3 = ent[k + 3];
-        Acc<VEC> x0 = load_row<VEC>(xb + (int64_t)e0.col * p.x_stride);
-        Acc<VEC> x1 = load_row<VEC>(xb + (int64_t)e1.col * p.x_stride);
-        Acc<VEC> x2 = load_row<VEC>(xb + (int64_t)e2.col * p.x_stride);
-        Acc<VEC> x3 = load_row<VEC>(xb + (int64_t)e3.col * p.x_stride);
-        mul_add<VEC>(acc, e0.val, x0);
-        mul_add<VEC>(acc, e1.val, x1);
-        mul_add<VEC>(acc, e2.val, x2);
-        mul_add<VEC>(acc, e3.val, x3);
-    }
-    for (; k < e; ++k) {
-        lgc_entry e0 = ent[k];
-        Acc<VEC> x0 = load_row<VEC>(xb + (int64_t)e0.col * p.x_stride);
-        mul_add<VEC>(acc, e0.val, x0);
-    }
-    finish_row<VEC>(p, row, c0, acc, rv);
+    finish_row<VEC, SpmmArgs>(p, row, c0, acc, rv);
 }
 
 // Long rows: one wavefront per chunk.  Lane group g takes entries begin+g, begin+g+G, ...;
@@ -464,15 +378,16 @@ __device__ __forceinline__ void chunks_body(const SpmmArgs &p, const lgc_chunk *
         Acc<VEC> rv;
         rv.zero();
         if (p.r != nullptr) rv = load_row<VEC>(p.r + (int64_t)ch.row * p.r_stride + c0);
-        finish_row<VEC>(p, ch.row, c0, acc, rv);
+        finish_row<VEC, SpmmArgs>(p, ch.row, c0, acc, rv);
     }
 }
 
 // One launch per operator and hop: the first `chunk_blocks` workgroups take the chunk work list (long rows
 // are dispatched first, they run longest), the rest the short rows.  Launching the two parts separately
 // left each one's ramp-up and tail exposed -- 7 back-to-back launches per hop of 4-45 us each on a rank of
-// an 8-way partition.  W = 0: short rows read their entries through rowptr (no slab for this width).
-template <int VEC, int W>
+// an 8-way partition.  The row part here reads its entries through the row pointer; it serves widths below 4 and
+// callers that ask for it -- rows of up to 32 entries normally go through the tiled kernels (lgc_spmm_tiles).
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void k_spmm_hop(SpmmArgs p, const lgc_chunk *__restrict__ chunks,
                                                     int32_t n_chunks, float *__restrict__ partials,
                                                     int32_t chunk_blocks) {
@@ -480,8 +395,7 @@ __global__ __launch_bounds__(kBlock) void k_spmm_hop(SpmmArgs p, const lgc_chunk
         chunks_body<VEC>(p, chunks, n_chunks, partials, blockIdx.x);
     } else {
         const int64_t block = (int64_t)blockIdx.x - chunk_blocks;
-        if constexpr (W == 0) rows_body<VEC>(p, block);
-        else rows_slab_body<VEC, W>(p, block);
+        rows_body<VEC>(p, block);
     }
 }
 
@@ -531,8 +445,281 @@ __global__ __launch_bounds__(kBlock) void k_spmm_combine(SpmmArgs p, const lgc_m
         Acc<VEC> rv;
         rv.zero();
         if (p.r != nullptr) rv = load_row<VEC>(p.r + (int64_t)mr.row * p.r_stride + c0);
-        finish_row<VEC>(p, mr.row, c0, acc, rv);
+        finish_row<VEC, SpmmArgs>(p, mr.row, c0, acc, rv);
     }
+}
+
+
+// ----------------------------------------------------------------------------------------
+// Rows with at most 32 entries, tiled: k_rows_tile
+// ----------------------------------------------------------------------------------------
+// A wave lives for several TILES.  A tile is 1 KiB * L of row heads laid out so that ONE coalesced dwordx4
+// per lane (per load k < L) brings the entries of R = 128 L / W rows, plus R row ids (the rows are listed in
+// a processing order chosen for L2 locality, so ids are explicit).  The next tile's loads are issued before the
+// current tile's gathers: a wave pays the HBM latency of the streamed operands once, not once per 4 rows --
+// the old one-batch-per-wave kernel kept a wave slot busy ~6 us for 1.3 KB of traffic whatever the gathers hit
+// (tools/exp_floor.py).  No row pointer is read: padding entries carry col = -1.
+//
+// parts = 2 (D a multiple of 64): the row is cut into two column halves of whole 128-B lines; workgroups on
+// XCDs 0-3 (blockIdx % 8) compute the first half of every row, XCDs 4-7 the second, so each XCD's L2 only
+// ever sees half of the gathered table's bytes.  Placement is a speed matter only: any mapping of workgroups
+// to XCDs gives the same result.
+struct TileArgs {
+    const int32_t *order;   // [n_tiles * R] row ids in processing order, -1 = padding slot
+    const int32_t *meta;    // [n_tiles] 4 x 8 bits: longest row of batch 0..3 of the tile (fast path only)
+    const u4 *slab;         // [n_tiles * L * 64] 16-byte pieces = 2 entries each
+    uint32_t x_bytes, y_bytes, r_bytes;   // table sizes for the buffer descriptors of the fast path
+    const float *x;
+    float *y;
+    const float *r;
+    int64_t x_stride, y_stride, r_stride;
+    float a, b;
+    int32_t n_tiles, tiles_per_wave;
+    int32_t parts, lpr;     // lanes per (part of a) row
+    int32_t part_col[2], part_dim[2];
+    int32_t wt_store;
+};
+
+template <int W, int L>
+__device__ __forceinline__ void tiles_body(const TileArgs &p, const int64_t block) {
+    constexpr int R = 128 * L / W;     // rows per tile
+    constexpr int Wk = W / L;          // entries of a row in one load
+    constexpr int PPR = Wk / 2;        // 16-byte pieces of a row in one load
+    const int lane = threadIdx.x & (kWave - 1);
+    int part = 0;
+    int64_t pblock = block;
+    if (p.parts == 2) {
+        const int xcd = (int)(block & 7);
+        part = xcd >> 2;
+        pblock = (block >> 3) * 4 + (xcd & 3);
+    }
+    const int64_t wave = pblock * (kBlock / kWave) + (threadIdx.x / kWave);
+    int64_t tile = wave * p.tiles_per_wave;
+    if (tile >= p.n_tiles) return;  // wave-uniform
+    const int64_t tile_end = min(tile + (int64_t)p.tiles_per_wave, (int64_t)p.n_tiles);
+    const int dim = p.part_dim[part];
+    const int G = kWave / p.lpr;       // rows per batch
+    const int g = lane / p.lpr;
+    const int l = lane - g * p.lpr;
+    const bool lane_on = g < G;
+    const int c0 = p.part_col[part] + min(l * 4, dim - 4);
+    const float *xb = p.x + c0;
+
+    u4 nxt[L];
+    int32_t nxt_rid = -1;
+#pragma unroll
+    for (int k = 0; k < L; ++k) nxt[k] = p.slab[(tile * L + k) * kWave + lane];
+    if (lane < R) nxt_rid = p.order[tile * R + lane];
+    for (; tile < tile_end; ++tile) {
+        u4 cur[L];
+#pragma unroll
+        for (int k = 0; k < L; ++k) cur[k] = nxt[k];
+        const int32_t cur_rid = nxt_rid;
+        if (tile + 1 < tile_end) {
+#pragma unroll
+            for (int k = 0; k < L; ++k) nxt[k] = p.slab[((tile + 1) * L + k) * kWave + lane];
+            if (lane < R) nxt_rid = p.order[(tile + 1) * R + lane];
+        }
+        for (int s0 = 0; s0 < R; s0 += G) {
+            const int s = s0 + g;
+            const bool slot_on = lane_on && s < R;
+            const int ss = slot_on ? s : 0;
+            const int32_t row = __shfl(cur_rid, ss);
+            const bool on = slot_on && row >= 0;
+            Acc<4> acc, rv;
+            acc.zero();
+            rv.zero();
+            if (on && p.r != nullptr) rv = load_row<4>(p.r + (int64_t)row * p.r_stride + c0);
+            bool more = true;
+#pragma unroll
+            for (int k = 0; k < L; ++k) {
+#pragma unroll
+                for (int j0 = 0; j0 < Wk; j0 += 4) {
+                    if (!more) continue;
+                    int32_t col[4];
+                    float val[4];
+                    Acc<4> xv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {  // every lane of the wave executes the shuffles
+                        const int src = ss * PPR + ((j0 + j) >> 1);
+                        col[j] = __shfl((int)(((j0 + j) & 1) ? cur[k].z : cur[k].x), src);
+                        val[j] = __int_as_float(__shfl((int)(((j0 + j) & 1) ? cur[k].w : cur[k].y), src));
+                    }
+                    // entries are packed at the front of a row: when no row of the batch has entry j0, none has more
+                    more = __ballot(on && col[0] >= 0) != 0;
+                    if (!more) continue;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (on && col[j] >= 0) xv[j] = load_row<4>(xb + (int64_t)col[j] * p.x_stride);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (on && col[j] >= 0) mul_add<4>(acc, val[j], xv[j]);
+                }
+            }
+            if (on) finish_row<4, TileArgs>(p, row, c0, acc, rv);
+        }
+    }
+}
+
+template <int W, int L>
+__global__ __launch_bounds__(kBlock) void k_rows_tile(TileArgs p) {
+    tiles_body<W, L>(p, blockIdx.x);
+}
+
+
+// Fast path for rows of 13..16 lanes (D = 49..64): no divergent control flow and ~7 VALU instructions per
+// gathered row instead of ~20 -- the bpermute version is bound by vector-ALU issue, not by memory
+// (profiles/r02_*: SQ busy 90 %, 20 VALU per VMEM instruction).
+//   * a lane group is one DPP row of 16 lanes and owns the pieces of ITS rows (slot 4g + bt = pieces
+//     16g + 4bt ..), so an entry reaches the group's lanes with v_mov_b32 row_newbcast:k, no LDS crossbar;
+//   * gathers and stores go through buffer descriptors with 32-bit offsets = mad24(row, stride, lane offset);
+//     a padding entry / padding row has the 24-bit id 0xFFFFFF, whose offset the host has checked to lie
+//     beyond the table: the hardware returns zeros for the load and drops the store;
+//   * how many entries a batch needs is wave-uniform metadata -> scalar branches.
+template <int K>
+__device__ __forceinline__ int bcast16(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, 0x150 + K, 0xf, 0xf, true);   // row_newbcast:K (gfx90a+)
+}
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <int W, int L>
+__device__ __forceinline__ void tiles_body_dpp(const TileArgs &p, const int64_t block) {
+    constexpr int R = 128 * L / W;     // rows per tile
+    constexpr int Wk = W / L;          // entries of a row in one load
+    constexpr int PPR = Wk / 2;        // 16-byte pieces of a row in one load
+    constexpr int B = R / 4;           // batches of 4 rows
+    static_assert(B * PPR == 16, "a lane group's rows fill its 16 lanes");
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wave = block * (kBlock / kWave) + (threadIdx.x / kWave);
+    int64_t tile = __builtin_amdgcn_readfirstlane((int)(wave * p.tiles_per_wave));
+    if (tile >= p.n_tiles) return;  // wave-uniform
+    const int64_t tile_end = min(tile + (int64_t)p.tiles_per_wave, (int64_t)p.n_tiles);
+    const int l = lane & 15;
+    const int c0 = min(l * 4, p.part_dim[0] - 4);
+    const auto xsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, p.x_bytes, 0x00020000);
+    const auto ysrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.y, 0, p.y_bytes, 0x00020000);
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.r, 0, p.r != nullptr ? p.r_bytes : 0u, 0x00020000);
+    const unsigned xoff = (unsigned)c0 * 4u;    // lpr == 16: every lane of the group owns a float4 of the row
+    const unsigned xs = (unsigned)p.x_stride * 4u, ys = (unsigned)p.y_stride * 4u, rs = (unsigned)p.r_stride * 4u;
+
+    u4 nxt[L];
+    int32_t nxt_rid = -1;
+#pragma unroll
+    for (int k = 0; k < L; ++k) nxt[k] = p.slab[(tile * L + k) * kWave + lane];
+    if (l < B) nxt_rid = p.order[tile * R + (lane >> 4) * B + l];
+    int32_t nxt_meta = p.meta[tile];
+    for (; tile < tile_end; ++tile) {
+        u4 cur[L];
+#pragma unroll
+        for (int k = 0; k < L; ++k) cur[k] = nxt[k];
+        const int32_t cur_rid = nxt_rid;
+        const int32_t meta = nxt_meta;
+        if (tile + 1 < tile_end) {
+#pragma unroll
+            for (int k = 0; k < L; ++k) nxt[k] = p.slab[((tile + 1) * L + k) * kWave + lane];
+            if (l < B) nxt_rid = p.order[(tile + 1) * R + (lane >> 4) * B + l];
+            nxt_meta = p.meta[tile + 1];
+        }
+#pragma unroll
+        for (int bt = 0; bt < B; ++bt) {
+            const int nmax = (meta >> (8 * bt)) & 0xFF;   // scalar
+            const int row24 = bt == 0 ? bcast16<0>(cur_rid) : bt == 1 ? bcast16<1>(cur_rid)
+                              : bt == 2 ? bcast16<2>(cur_rid) : bcast16<3>(cur_rid);
+            f2 a0 = {0.0f, 0.0f}, a1 = {0.0f, 0.0f};
+            f4 rv = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (p.r != nullptr)
+                rv = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, __umul24(row24, rs) + xoff, 0, 0));
+#pragma unroll
+            for (int k = 0; k < L; ++k) {
+#pragma unroll
+                for (int j0 = 0; j0 < Wk; j0 += 4) {
+                    if (k * Wk + j0 < nmax) {     // wave-uniform
+                        f4 xv[4];
+                        float val[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int colbits = ((j0 + j) & 1) ? (int)cur[k].z : (int)cur[k].x;
+                            const int valbits = ((j0 + j) & 1) ? (int)cur[k].w : (int)cur[k].y;
+                            int col, vb;
+                            switch (bt * PPR + ((j0 + j) >> 1)) {   // compile-time after unrolling
+                                case 0: col = bcast16<0>(colbits); vb = bcast16<0>(valbits); break;
+                                case 1: col = bcast16<1>(colbits); vb = bcast16<1>(valbits); break;
+                                case 2: col = bcast16<2>(colbits); vb = bcast16<2>(valbits); break;
+                                case 3: col = bcast16<3>(colbits); vb = bcast16<3>(valbits); break;
+                                case 4: col = bcast16<4>(colbits); vb = bcast16<4>(valbits); break;
+                                case 5: col = bcast16<5>(colbits); vb = bcast16<5>(valbits); break;
+                                case 6: col = bcast16<6>(colbits); vb = bcast16<6>(valbits); break;
+                                case 7: col = bcast16<7>(colbits); vb = bcast16<7>(valbits); break;
+                                case 8: col = bcast16<8>(colbits); vb = bcast16<8>(valbits); break;
+                                case 9: col = bcast16<9>(colbits); vb = bcast16<9>(valbits); break;
+                                case 10: col = bcast16<10>(colbits); vb = bcast16<10>(valbits); break;
+                                case 11: col = bcast16<11>(colbits); vb = bcast16<11>(valbits); break;
+                                case 12: col = bcast16<12>(colbits); vb = bcast16<12>(valbits); break;
+                                case 13: col = bcast16<13>(colbits); vb = bcast16<13>(valbits); break;
+                                case 14: col = bcast16<14>(colbits); vb = bcast16<14>(valbits); break;
+                                default: col = bcast16<15>(colbits); vb = bcast16<15>(valbits); break;
+                            }
+                            val[j] = __int_as_float(vb);
+                            xv[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, __umul24(col, xs) + xoff, 0, 0));
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {   // product rounded, then added (no FMA: -ffp-contract=off)
+                            const f2 v2 = {val[j], val[j]};
+                            const f2 lo = {xv[j].x, xv[j].y}, hi = {xv[j].z, xv[j].w};
+                            a0 = a0 + lo * v2;
+                            a1 = a1 + hi * v2;
+                        }
+                    }
+                }
+            }
+            Acc<4> acc;
+            acc.v[0] = a0.x; acc.v[1] = a0.y; acc.v[2] = a1.x; acc.v[3] = a1.y;
+            if (p.a != 1.0f) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc.v[i] = __fmul_rn(p.a, acc.v[i]);
+            }
+            if (p.r != nullptr) {
+                acc.v[0] = __fadd_rn(acc.v[0], __fmul_rn(p.b, rv.x));
+                acc.v[1] = __fadd_rn(acc.v[1], __fmul_rn(p.b, rv.y));
+                acc.v[2] = __fadd_rn(acc.v[2], __fmul_rn(p.b, rv.z));
+                acc.v[3] = __fadd_rn(acc.v[3], __fmul_rn(p.b, rv.w));
+            }
+            const f4 o = {acc.v[0], acc.v[1], acc.v[2], acc.v[3]};
+            // sc1 write-through: the output row is not read again in this launch (the host made sure of < 4 GiB)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o), ysrc, __umul24(row24, ys) + xoff, 0, 16);
+        }
+    }
+}
+
+template <int W, int L>
+__global__ __launch_bounds__(kBlock) void k_rows_tile_dpp(TileArgs p) {
+    tiles_body_dpp<W, L>(p, blockIdx.x);
+}
+
+// order + CSR -> tile layout: piece ((t*L + k)*R + s)*PPR + q holds entries k*Wk + 2q, +1 of the row in slot s of tile t
+__global__ void k_build_tiles(const int32_t *__restrict__ rowptr, const lgc_entry *__restrict__ entries,
+                              const int32_t *__restrict__ order, int64_t n_slots, int32_t W, int32_t L,
+                              lgc_entry *__restrict__ slab) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per slab entry
+    if (i >= n_slots * W) return;
+    const int R = 128 * L / W, Wk = W / L;
+    const int jj = (int)(i % Wk);
+    int64_t rest = i / Wk;
+    const int s = (int)(rest % R);
+    rest /= R;
+    const int k = (int)(rest % L);
+    const int64_t t = rest / L;
+    const int32_t row = order[t * R + s];
+    lgc_entry v;
+    v.col = -1;
+    v.val = 0.0f;
+    if (row >= 0) {
+        const int32_t b = rowptr[row], e = rowptr[row + 1];
+        const int j = k * Wk + jj;
+        if (b + j < e) v = entries[b + j];
+    }
+    slab[i] = v;
 }
 
 struct LincombArgs {
@@ -751,18 +938,9 @@ int lgc_build_csr(const int64_t *edge_index, const float *edge_weight, int64_t n
     return (int)hipGetLastError();
 }
 
-int lgc_build_slab(const int32_t *rowptr, const lgc_entry *entries, int64_t n_rows, int32_t width, lgc_entry *slab,
-                   void *stream_) {
-    if (!rowptr || !slab || n_rows < 0 || width != 8) return LGC_E_INVAL;
-    if (n_rows == 0) return 0;
-    hipLaunchKernelGGL(k_build_slab, dim3(ceil_div(n_rows * width, kBlock)), dim3(kBlock), 0, as_stream(stream_),
-                       rowptr, entries, n_rows, width, slab);
-    return (int)hipGetLastError();
-}
-
 int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin, int32_t row_end, int32_t short_max,
              const lgc_chunk *chunks, int32_t n_chunks, const lgc_multi_row *multi, int32_t n_multi, float *partials,
-             const lgc_entry *slab, int32_t slab_width, int64_t table_rows, const float *x, int64_t x_stride, float *y, int64_t y_stride, const float *r, int64_t r_stride, float a,
+             int64_t table_rows, const float *x, int64_t x_stride, float *y, int64_t y_stride, const float *r, int64_t r_stride, float a,
              float b, int32_t dim, void *stream_) {
     DimCfg cfg;
     if (!dim_cfg(dim, &cfg)) return LGC_E_DIM;
@@ -776,10 +954,8 @@ int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin,
     // allocations) are the fast case, nothing else is rejected
     if (!aligned_to(x, 4) || !aligned_to(y, 4) || (r && !aligned_to(r, 4))) return LGC_E_ALIGN;
     hipStream_t stream = as_stream(stream_);
-    if (slab && slab_width != 8) return LGC_E_INVAL;
-    const bool use_slab = slab != nullptr && cfg.vec == 4 && cfg.lpr >= slab_width;
     SpmmArgs p{rowptr, entries, x, y, r, x_stride, y_stride, r_stride, a, b, dim, cfg.lpr, row_begin, row_end,
-               short_max, use_slab ? slab : nullptr, use_slab ? slab_width : 0, 0};
+               short_max, 0};
     // write-through output stores address y with 32-bit byte offsets
     p.wt_store = (table_rows * y_stride * 4 < (int64_t(1) << 32)) ? 1 : 0;
     const int waves_per_block = kBlock / kWave;
@@ -791,14 +967,7 @@ int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin,
         const int chunk_blocks = n_chunks > 0 ? ceil_div(n_chunks, waves_per_block) : 0;
         const dim3 grid(row_blocks + chunk_blocks);
         if (grid.x > 0) {
-            if constexpr (V == 4) {
-                if (p.slab_width == 8)
-                    hipLaunchKernelGGL((k_spmm_hop<4, 8>), grid, dim3(kBlock), 0, stream, p, chunks, n_chunks, partials, chunk_blocks);
-                else
-                    hipLaunchKernelGGL((k_spmm_hop<4, 0>), grid, dim3(kBlock), 0, stream, p, chunks, n_chunks, partials, chunk_blocks);
-            } else {
-                hipLaunchKernelGGL((k_spmm_hop<1, 0>), grid, dim3(kBlock), 0, stream, p, chunks, n_chunks, partials, chunk_blocks);
-            }
+            hipLaunchKernelGGL((k_spmm_hop<V>), grid, dim3(kBlock), 0, stream, p, chunks, n_chunks, partials, chunk_blocks);
         }
         if (n_multi > 0) {
             int blocks = ceil_div(n_multi, waves_per_block);
@@ -807,6 +976,71 @@ int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin,
         }
         return (int)hipGetLastError();
     });
+}
+
+int lgc_build_tiles(const int32_t *rowptr, const lgc_entry *entries, const int32_t *order, int64_t n_slots, int32_t width,
+                    lgc_entry *slab, void *stream_) {
+    if (!rowptr || !order || !slab || n_slots < 0 || (width != 8 && width != 16 && width != 32)) return LGC_E_INVAL;
+    const int L = width == 32 ? 2 : 1;
+    if (n_slots % (128 * L / width) != 0) return LGC_E_INVAL;
+    if (n_slots == 0) return 0;
+    hipLaunchKernelGGL(k_build_tiles, dim3(ceil_div(n_slots * width, kBlock)), dim3(kBlock), 0, as_stream(stream_), rowptr,
+                       entries, order, n_slots, width, L, slab);
+    return (int)hipGetLastError();
+}
+
+int lgc_spmm_tiles(const int32_t *order, const int32_t *meta, const lgc_entry *slab, int32_t n_tiles, int32_t width,
+                   int32_t tiles_per_wave, int32_t parts, int64_t table_rows, const float *x, int64_t x_stride, float *y, int64_t y_stride,
+                   const float *r, int64_t r_stride, float a, float b, int32_t dim, void *stream_) {
+    if (dim < 4 || dim > 256) return LGC_E_DIM;
+    if (!order || !slab || !x || !y || n_tiles < 0 || tiles_per_wave < 1 || (parts != 1 && parts != 2) || x == y)
+        return LGC_E_INVAL;
+    if (width != 8 && width != 16 && width != 32) return LGC_E_INVAL;
+    if (x_stride < dim || y_stride < dim || (r && r_stride < dim)) return LGC_E_INVAL;
+    if (!aligned_to(x, 4) || !aligned_to(y, 4) || (r && !aligned_to(r, 4)) || !aligned_to(slab, 16)) return LGC_E_ALIGN;
+    if (parts == 2 && (dim % 8 != 0)) return LGC_E_INVAL;
+    if (n_tiles == 0) return 0;
+    TileArgs p{};
+    p.order = order;
+    p.slab = reinterpret_cast<const u4 *>(slab);
+    p.x = x; p.y = y; p.r = r;
+    p.x_stride = x_stride; p.y_stride = y_stride; p.r_stride = r_stride;
+    p.a = a; p.b = b;
+    p.n_tiles = n_tiles; p.tiles_per_wave = tiles_per_wave;
+    p.parts = parts;
+    const int pd = dim / parts;
+    p.part_col[0] = 0; p.part_dim[0] = pd;
+    p.part_col[1] = pd; p.part_dim[1] = dim - pd;
+    p.lpr = (pd + 3) / 4;
+    p.wt_store = (table_rows * y_stride * 4 < (int64_t(1) << 32)) ? 1 : 0;
+    p.meta = meta;
+    const int64_t waves = ((int64_t)n_tiles + tiles_per_wave - 1) / tiles_per_wave;
+    int64_t blocks = (waves + 3) / 4;
+    hipStream_t stream = as_stream(stream_);
+    // fast path: 16-lane rows, 24-bit row ids, 32-bit byte offsets, and the padding id 0xFFFFFF must fall outside
+    // every table so that the hardware's range check turns padding into "load zeros / drop the store"
+    auto table_bytes = [&](int64_t stride) { return ((table_rows - 1) * stride + dim) * 4; };
+    auto pad_is_oob = [&](int64_t stride) {
+        const uint32_t pad = (uint32_t)(0xFFFFFFull * (uint64_t)(stride * 4));
+        return stride * 4 < (1 << 24) && table_bytes(stride) < (int64_t(1) << 32) && (int64_t)pad >= table_bytes(stride);
+    };
+    const bool fast = meta != nullptr && parts == 1 && dim >= 61 && dim <= 64 && table_rows > 0 && table_rows < 0xFFFFFF &&
+                      pad_is_oob(x_stride) && pad_is_oob(y_stride) && (!r || pad_is_oob(r_stride)) &&
+                      getenv("LGCN_NO_FAST_TILES") == nullptr;
+    if (fast) {
+        p.x_bytes = (uint32_t)table_bytes(x_stride);
+        p.y_bytes = (uint32_t)table_bytes(y_stride);
+        p.r_bytes = r ? (uint32_t)table_bytes(r_stride) : 0u;
+        if (width == 8) hipLaunchKernelGGL((k_rows_tile_dpp<8, 1>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, p);
+        else if (width == 16) hipLaunchKernelGGL((k_rows_tile_dpp<16, 1>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, p);
+        else hipLaunchKernelGGL((k_rows_tile_dpp<32, 2>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, p);
+        return (int)hipGetLastError();
+    }
+    if (parts == 2) blocks = ((blocks + 3) / 4) * 8;   // XCDs 0-3 and 4-7 each get ceil(blocks / 4) * 4 workgroups
+    if (width == 8) hipLaunchKernelGGL((k_rows_tile<8, 1>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, p);
+    else if (width == 16) hipLaunchKernelGGL((k_rows_tile<16, 1>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, p);
+    else hipLaunchKernelGGL((k_rows_tile<32, 2>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, p);
+    return (int)hipGetLastError();
 }
 
 int lgc_lincomb(float *y, int64_t y_stride, const float *const *src, const int64_t *src_stride, const float *coef,

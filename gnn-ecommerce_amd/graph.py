@@ -8,6 +8,9 @@ and the result is kept in a small cache keyed on tensor identity and version cou
 Layout in HBM (per operator; A for the forward pass, A^T built lazily for the backward pass):
     rowptr   int32 [N+1]
     entries  {int32 col, fp32 val} [E]   8 B per edge, rows in edge order
+    tiles    per width class W in (8, 16, 32): rows with at most W entries in PROCESSING ORDER --
+             order int32 [slots] (row ids, -1 = padding), meta int32 [tiles] (batch lengths),
+             slab {col, val} [slots * W] in the 1 KiB-piece layout of lgc_build_tiles
     chunks   {row, begin, end, slot} int32 [C]   work list for rows longer than ``short_max``
     multi    {row, slot_begin, slot_end, 0} int32 [M]   rows cut into several chunks
     partials fp32 [n_slots, D]   scratch for those rows (allocated per width on first use)
@@ -17,7 +20,7 @@ from __future__ import annotations
 import os
 from collections import OrderedDict
 from dataclasses import dataclass, field
-from typing import Dict, Optional, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 from torch import Tensor
@@ -28,8 +31,14 @@ from . import _native
 # are cut into chunks of about CHUNK_LEN entries, one wavefront each.
 SHORT_MAX = int(os.environ.get("LGCN_SHORT_MAX", "32"))
 CHUNK_LEN = int(os.environ.get("LGCN_CHUNK_LEN", "256"))
-# Width of the fixed slab of row heads the short-row kernel reads: 8 entries (0 = off).
-SLAB_WIDTH = int(os.environ.get("LGCN_SLAB_WIDTH", "8"))
+# Rows of up to 32 entries go through the tiled kernels (lgc_spmm_tiles) in width classes of 8 / 16 / 32 entries.
+TILE_WIDTHS = (8, 16, 32)
+USE_TILES = os.environ.get("LGCN_TILES", "1") == "1"
+TILES_PER_WAVE = int(os.environ.get("LGCN_TILES_PER_WAVE", "1"))      # 1 ~ 2 > 4 on the full-size user step
+# Processing order of the tiled rows.  "cold": rows sorted by their least-gathered column, so the rows that
+# share a rarely used table row run close together in time and that row crosses the fabric about once
+# (an LRU model of one 4 MiB L2 gives 47 % -> 63 % hits on the user step); "natural": row order.
+TILE_ORDER = os.environ.get("LGCN_TILE_ORDER", "cold")
 
 
 @dataclass
@@ -89,16 +98,126 @@ def build_row_plan(rowptr: Tensor, row_begin: int, row_end: int,
     return RowPlan(row_begin, row_end, short_max, chunks, multi, int(mnch.sum().item()))
 
 
+
+def tile_geometry(width: int) -> Tuple[int, int]:
+    """(rows per tile R, batches of four rows B) of a width class: a tile is 1 KiB of row heads (2 KiB for 32)."""
+    if width not in TILE_WIDTHS:
+        raise ValueError(f"tile width must be one of {TILE_WIDTHS}")
+    rows = 128 * (2 if width == 32 else 1) // width
+    return rows, rows // 4
+
+
+def plan_tile_classes(rowptr: Tensor, columns: Tensor, row_begin: int, row_end: int, max_len: int,
+                      mode: str = "cold") -> List[Tuple[int, Tensor, Tensor]]:
+    """Pure index arithmetic (any device; unit-tested on CPU): [(width, order, meta)] for the rows of
+    [row_begin, row_end) with at most min(max_len, 32) entries.
+
+    A row goes to the narrowest class that holds it (0 entries -> width 8: its output is still written).
+    ``order``: int32, padded with -1 to whole tiles; inside a tile the longest rows come first and rank rho sits in
+    slot (rho % 4) * B + rho // 4, i.e. lane group rho % 4, batch rho // 4 -- the four rows of a batch have similar
+    lengths.  ``meta``: int32 per tile, byte bt = longest row of batch bt (how many entries the batch gathers).
+    """
+    dev = rowptr.device
+    rp = rowptr[row_begin:row_end + 1].to(torch.int64)
+    deg = rp[1:] - rp[:-1]
+    n = row_end - row_begin
+    cap = min(int(max_len), TILE_WIDTHS[-1])
+    key = None
+    if mode == "cold" and n > 0 and int(rp[-1] - rp[0]) > 0:
+        cols = columns[int(rp[0]):int(rp[-1])].to(torch.int64)
+        pop = torch.bincount(cols)
+        rows = torch.repeat_interleave(torch.arange(n, device=dev), deg)
+        k = pop[cols] * (int(cols.max()) + 1) + cols                   # popularity major, column id minor
+        key = torch.full((n,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=dev)
+        key.scatter_reduce_(0, rows, k, "amin")
+    elif mode not in ("cold", "natural"):
+        raise ValueError("tile order must be 'cold' or 'natural'")
+    out = []
+    lo = -1
+    for width in TILE_WIDTHS:
+        hi = min(width, cap)
+        sel = torch.nonzero((deg > lo) & (deg <= hi)).flatten()
+        lo = max(lo, hi)
+        if sel.numel() == 0:
+            continue
+        if key is not None:
+            sel = sel[torch.argsort(key[sel], stable=True)]
+        r_tile, b_tile = tile_geometry(width)
+        pad = (-sel.numel()) % r_tile
+        rows_p = torch.cat([sel, torch.full((pad,), -1, dtype=torch.int64, device=dev)]).view(-1, r_tile)
+        d = torch.where(rows_p >= 0, deg[rows_p.clamp(min=0)], torch.full_like(rows_p, -1))   # padding sorts last
+        rank = torch.argsort(d, dim=1, descending=True, stable=True)
+        rows_s, d_s = torch.gather(rows_p, 1, rank), torch.gather(d, 1, rank).clamp(min=0)
+        rho = torch.arange(r_tile, device=dev)
+        slot = (rho % 4) * b_tile + rho // 4
+        placed = torch.empty_like(rows_s)
+        placed[:, slot] = rows_s
+        bmax = d_s.view(-1, b_tile, 4).amax(dim=2)
+        meta = (bmax << (8 * torch.arange(b_tile, device=dev)).view(1, -1)).sum(dim=1)
+        order = torch.where(placed >= 0, placed + row_begin, placed)
+        out.append((width, order.reshape(-1).to(torch.int32).contiguous(), meta.to(torch.int32).contiguous()))
+    return out
+
+
+@dataclass
+class TileClass:
+    """Rows of one width class in the device layout of lgc_build_tiles."""
+    width: int
+    order: Tensor       # int32 [n_tiles * R]
+    meta: Tensor        # int32 [n_tiles]
+    slab: Tensor        # int32 [n_tiles * R * width, 2]
+
+    @property
+    def n_tiles(self) -> int:
+        return self.meta.numel()
+
+
+def build_tile_classes(rowptr: Tensor, entries: Tensor, row_begin: int, row_end: int, max_len: int,
+                       mode: Optional[str] = None) -> List[TileClass]:
+    lib = _native.load()
+    classes = []
+    for width, order, meta in plan_tile_classes(rowptr, entries[:, 0], row_begin, row_end, max_len, mode or TILE_ORDER):
+        slab = torch.empty((order.numel() * width, 2), dtype=torch.int32, device=rowptr.device)
+        with torch.cuda.device(rowptr.device):
+            code = lib.lgc_build_tiles(_native.ptr(rowptr), _native.ptr(entries), _native.ptr(order), order.numel(), width,
+                                       _native.ptr(slab), _native.stream_of(rowptr.device))
+        _native.check(code, "lgc_build_tiles")
+        classes.append(TileClass(width, order, meta, slab))
+    return classes
+
+
 @dataclass
 class Operator:
-    """One sparse operator ready to be applied: CSR + plan (+ per-width scratch)."""
+    """One sparse operator ready to be applied: CSR + plan (+ per-width scratch).
+
+    ``plan`` covers rows [row_begin, row_end): rows longer than ``plan.short_max`` as chunks; the shorter ones run
+    through the tiled kernels when ``tiles`` is given (dim >= 4), else through lgc_spmm's row part."""
     n_rows: int
     rowptr: Tensor
     entries: Tensor                      # int32 [E, 2]: column, fp32 bits of the value
     plan: RowPlan
-    slab: Optional[Tensor] = None        # int32 [n_rows * W, 2]: heads of every row, padded (lgc_build_slab)
-    slab_width: int = 0
+    tiled: bool = False                  # rows up to plan.short_max go through the tiled kernels
+    _tiles: Optional[List[TileClass]] = None
     _partials: Dict[int, Tensor] = field(default_factory=dict)
+
+    @classmethod
+    def build(cls, n_rows: int, rowptr: Tensor, entries: Tensor, row_begin: int, row_end: int,
+              short_max: int = SHORT_MAX, chunk_len: int = CHUNK_LEN, tiles: Optional[bool] = None) -> "Operator":
+        """Work plan for rows [row_begin, row_end) of a CSR.  With tiles, every row of at most
+        min(short_max, 32) entries is a tiled row and every longer one is chunked."""
+        use_tiles = USE_TILES if tiles is None else tiles
+        if use_tiles and rowptr.is_cuda:
+            short_max = min(short_max, TILE_WIDTHS[-1])
+        return cls(n_rows, rowptr, entries, build_row_plan(rowptr, row_begin, row_end, short_max, chunk_len),
+                   bool(use_tiles and rowptr.is_cuda))
+
+    @property
+    def tiles(self) -> List[TileClass]:
+        """Built on first use: an operator that is only ever restricted to sub-ranges never pays for it."""
+        if self._tiles is None:
+            p = self.plan
+            self._tiles = build_tile_classes(self.rowptr, self.entries, p.row_begin, p.row_end, p.short_max)
+        return self._tiles
 
     @property
     def nnz(self) -> int:
@@ -137,16 +256,26 @@ class Operator:
         p = self.plan
         partials = self.partials(dim)
         table_rows = min(x.size(0), out.size(0))
+        tiled = self.tiled and dim >= 4
+        r_ptr, r_stride = _native.ptr(r), (0 if r is None else r.stride(0))
+        stream = _native.stream_of(x.device)
         with torch.cuda.device(x.device):
-            code = lib.lgc_spmm(
-                _native.ptr(self.rowptr), _native.ptr(self.entries), p.row_begin, p.row_end, p.short_max,
-                _native.ptr(p.chunks) if p.n_chunks else None, p.n_chunks,
-                _native.ptr(p.multi) if p.n_multi else None, p.n_multi, _native.ptr(partials),
-                _native.ptr(self.slab), self.slab_width, table_rows,
-                _native.ptr(x), x.stride(0), _native.ptr(out), out.stride(0),
-                _native.ptr(r), 0 if r is None else r.stride(0), float(a), float(b), dim,
-                _native.stream_of(x.device))
-        _native.check(code, "lgc_spmm")
+            # long rows first (they run longest); with tiles the row part of lgc_spmm gets an empty range
+            if not tiled or p.n_chunks:
+                code = lib.lgc_spmm(
+                    _native.ptr(self.rowptr), _native.ptr(self.entries), p.row_begin, p.row_begin if tiled else p.row_end,
+                    p.short_max, _native.ptr(p.chunks) if p.n_chunks else None, p.n_chunks,
+                    _native.ptr(p.multi) if p.n_multi else None, p.n_multi, _native.ptr(partials), table_rows,
+                    _native.ptr(x), x.stride(0), _native.ptr(out), out.stride(0), r_ptr, r_stride, float(a), float(b),
+                    dim, stream)
+                _native.check(code, "lgc_spmm")
+            if tiled:
+                for tc in self.tiles:
+                    code = lib.lgc_spmm_tiles(
+                        _native.ptr(tc.order), _native.ptr(tc.meta), _native.ptr(tc.slab), tc.n_tiles, tc.width,
+                        TILES_PER_WAVE, 1, table_rows, _native.ptr(x), x.stride(0), _native.ptr(out), out.stride(0),
+                        r_ptr, r_stride, float(a), float(b), dim, stream)
+                    _native.check(code, "lgc_spmm_tiles")
         return out
 
 
@@ -215,16 +344,7 @@ class PropGraph:
         if int(self.status[0].item()) & _native.ST_INDEX_OOB:
             raise IndexError(f"edge_index contains node ids outside [0, {n})")
         lo, hi = row_range if row_range is not None else (0, n)
-        plan = build_row_plan(rowptr, lo, hi, self.short_max, self.chunk_len)
-        slab, width = None, 0
-        if SLAB_WIDTH and e > 0:
-            width = SLAB_WIDTH
-            slab = torch.empty((n * width, 2), dtype=torch.int32, device=self.device)
-            with torch.cuda.device(self.device):
-                code = lib.lgc_build_slab(_native.ptr(rowptr), _native.ptr(entries), n, width, _native.ptr(slab),
-                                          _native.stream_of(self.device))
-            _native.check(code, "lgc_build_slab")
-        return Operator(n, rowptr, entries, plan, slab, width)
+        return Operator.build(n, rowptr, entries, lo, hi, self.short_max, self.chunk_len)
 
     def _find_bipartite_split(self) -> Optional[int]:
         """s such that every edge joins a node < s ("users") with a node >= s ("items") -- the layout of
@@ -244,9 +364,7 @@ class PropGraph:
         got = self._halves.get(transpose)
         if got is None:
             op = self.transpose_op if transpose else self.forward_op
-            got = tuple(Operator(op.n_rows, op.rowptr, op.entries,
-                                 build_row_plan(op.rowptr, lo, hi, self.short_max, self.chunk_len),
-                                 op.slab, op.slab_width)
+            got = tuple(Operator.build(op.n_rows, op.rowptr, op.entries, lo, hi, self.short_max, self.chunk_len)
                         for lo, hi in ((0, self.split), (self.split, self.num_nodes)))
             self._halves[transpose] = got
         return got
@@ -263,18 +381,42 @@ class PropGraph:
 
     # -- persistence: a built graph as a flat safetensors file ------------------
     def save(self, path: str) -> None:
-        """Write the forward operator (CSR, slab), degrees and metadata; nothing executable in the file.
+        """Write the forward operator's CSR, degrees and metadata; nothing executable in the file.
         A serving worker can ``PropGraph.load`` it instead of re-reading the CSV, rebuilding the COO
-        (torchserve/lightgcn_handler.py:32-38) and sorting it again."""
+        (torchserve/lightgcn_handler.py:32-38) and sorting it again.  The tile layout is derived data and is
+        rebuilt at load time (milliseconds on the device)."""
         from safetensors.torch import save_file
         op = self.forward_op
         tensors = {"rowptr": op.rowptr, "entries": op.entries, "deg": self.deg, "dis": self.dis}
-        if op.slab is not None:
-            tensors["slab"] = op.slab
-        meta = {"format": "lgcn-graph-1", "num_nodes": str(self.num_nodes), "num_edges": str(self.num_edges),
-                "normalize": str(int(self.normalize)), "slab_width": str(op.slab_width),
-                "split": "" if self.split is None else str(self.split)}
+        meta = {"format": "lgcn-graph-2", "num_nodes": str(self.num_nodes), "num_edges": str(self.num_edges),
+                "normalize": str(int(self.normalize)), "split": "" if self.split is None else str(self.split)}
         save_file({k: v.detach().cpu().contiguous() for k, v in tensors.items()}, path, metadata=meta)
+
+    @staticmethod
+    def validate_csr(rowptr: Tensor, entries: Tensor, deg: Tensor, dis: Tensor, num_nodes: int, num_edges: int,
+                     split: Optional[int], where: str) -> None:
+        """Everything the kernels take on trust, checked once: a truncated, stale or corrupt file must end in a
+        ValueError here, not in an out-of-range gather on the device."""
+        def bad(msg):
+            raise ValueError(f"{where}: {msg}")
+        if num_nodes < 0 or num_edges < 0 or num_nodes >= 2 ** 31 - 1 or num_edges >= 2 ** 31 - 1:
+            bad("node or edge count out of range")
+        if rowptr.dtype != torch.int32 or rowptr.shape != (num_nodes + 1,):
+            bad(f"rowptr must be int32 [{num_nodes + 1}], got {rowptr.dtype} {tuple(rowptr.shape)}")
+        if entries.dtype != torch.int32 or entries.shape != (num_edges, 2):
+            bad(f"entries must be int32 [{num_edges}, 2], got {entries.dtype} {tuple(entries.shape)}")
+        for name, t in (("deg", deg), ("dis", dis)):
+            if t.dtype != torch.float32 or t.shape != (num_nodes,):
+                bad(f"{name} must be fp32 [{num_nodes}], got {t.dtype} {tuple(t.shape)}")
+        if split is not None and not 0 < split < num_nodes:
+            bad(f"bipartite split {split} outside (0, {num_nodes})")
+        rp = rowptr.to(torch.int64)
+        checks = [rp[0] == 0, rp[-1] == num_edges, (rp[1:] >= rp[:-1]).all()]
+        if num_edges:
+            col = entries[:, 0]
+            checks += [col.min() >= 0, col.max() < num_nodes]
+        if not bool(torch.stack([c.reshape(()) for c in checks]).all().item()):     # one host sync
+            bad("row pointer is not a non-decreasing 0 .. num_edges sequence, or a column id is outside the graph")
 
     @classmethod
     def load(cls, path: str, device, short_max: int = SHORT_MAX, chunk_len: int = CHUNK_LEN) -> "PropGraph":
@@ -286,31 +428,37 @@ class PropGraph:
             raise _native.NativeLibraryError("graphs are loaded onto a ROCm device only (no CPU fallback)")
         with safe_open(path, framework="pt", device="cpu") as f:
             meta = f.metadata() or {}
-            if meta.get("format") != "lgcn-graph-1":
+            if meta.get("format") not in ("lgcn-graph-1", "lgcn-graph-2"):
                 raise ValueError(f"{path} is not a saved propagation graph")
             t = {k: f.get_tensor(k) for k in f.keys()}
+        for k in ("rowptr", "entries", "deg", "dis"):
+            if k not in t:
+                raise ValueError(f"{path}: tensor {k!r} is missing")
+        try:
+            num_nodes, num_edges = int(meta["num_nodes"]), int(meta["num_edges"])
+            normalize = bool(int(meta["normalize"]))
+            split = int(meta["split"]) if meta.get("split") else None
+        except (KeyError, ValueError) as exc:
+            raise ValueError(f"{path}: bad metadata ({exc})") from exc
         g = cls.__new__(cls)
-        g.device, g.num_nodes, g.num_edges = device, int(meta["num_nodes"]), int(meta["num_edges"])
-        g.normalize = bool(int(meta["normalize"]))
+        g.device, g.num_nodes, g.num_edges, g.normalize = device, num_nodes, num_edges, normalize
         g.short_max, g.chunk_len = short_max, chunk_len
         g._key_refs = g._edge_index = g._edge_weight = None
         g.status = torch.zeros(4, dtype=torch.int32, device=device)
-        g.deg, g.dis, g.edge_values = t["deg"].to(device), t["dis"].to(device), None
         rowptr, entries = t["rowptr"].to(device), t["entries"].to(device)
-        if rowptr.dtype != torch.int32 or rowptr.numel() != g.num_nodes + 1 or entries.shape != (g.num_edges, 2):
-            raise ValueError(f"{path}: inconsistent tensor shapes")
-        slab = t["slab"].to(device) if "slab" in t else None
-        g.forward_op = Operator(g.num_nodes, rowptr, entries,
-                                build_row_plan(rowptr, 0, g.num_nodes, short_max, chunk_len), slab,
-                                int(meta.get("slab_width", "0")) if slab is not None else 0)
+        g.deg, g.dis, g.edge_values = t["deg"].to(device), t["dis"].to(device), None
+        cls.validate_csr(rowptr, entries, g.deg, g.dis, num_nodes, num_edges, split, path)
+        g.forward_op = Operator.build(num_nodes, rowptr, entries, 0, num_nodes, short_max, chunk_len)
         g._transpose_op = None
-        g.split = int(meta["split"]) if meta.get("split") else None
+        g.split = split
         g._halves = {}
         return g
 
     def nbytes(self) -> int:
         ops = [self.forward_op] + ([self._transpose_op] if self._transpose_op is not None else [])
-        return sum(o.rowptr.numel() * 4 + o.entries.numel() * 4 + o.plan.chunks.numel() * 4 for o in ops)
+        return sum(o.rowptr.numel() * 4 + o.entries.numel() * 4 + o.plan.chunks.numel() * 4
+                   + sum(tc.slab.numel() * 4 + tc.order.numel() * 4 + tc.meta.numel() * 4 for tc in (o._tiles or []))
+                   for o in ops)
 
 
 # ----------------------------------------------------------------------------------------
@@ -321,7 +469,8 @@ _CACHE_SIZE = int(os.environ.get("LGCN_GRAPH_CACHE", "4"))
 
 
 def _key(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int, normalize: bool) -> tuple:
-    w = None if edge_weight is None else (edge_weight.data_ptr(), edge_weight._version, tuple(edge_weight.shape))
+    w = None if edge_weight is None else (edge_weight.data_ptr(), edge_weight._version, tuple(edge_weight.shape),
+                                          tuple(edge_weight.stride()))
     return (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), tuple(edge_index.stride()),
             str(edge_index.device), w, int(num_nodes), bool(normalize))
 

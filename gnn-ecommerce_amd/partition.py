@@ -76,8 +76,7 @@ class HipOps:
 
     def restrict(self, op: Operator, row_begin: int, row_end: int, short_max: int = SHORT_MAX) -> Operator:
         """The same CSR, work plan limited to rows [row_begin, row_end)."""
-        return Operator(op.n_rows, op.rowptr, op.entries,
-                        build_row_plan(op.rowptr, row_begin, row_end, short_max, CHUNK_LEN), op.slab, op.slab_width)
+        return Operator.build(op.n_rows, op.rowptr, op.entries, row_begin, row_end, short_max, CHUNK_LEN)
 
     def apply(self, op: Operator, x: Tensor, out: Tensor, a: float, r: Optional[Tensor], b: float) -> None:
         op.apply(x, out, a=a, r=r, b=b)

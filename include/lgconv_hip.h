@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LGC_ABI_VERSION 4
+#define LGC_ABI_VERSION 5
 
 /* argument errors (negative return values) */
 #define LGC_E_INVAL      (-1)  /* null pointer, negative size, bad flag                    */
@@ -106,13 +106,33 @@ int lgc_build_csr(const int64_t *edge_index, const float *edge_weight,
                   void *workspace, size_t workspace_bytes,
                   int32_t *status, void *stream);
 
-/* Fixed-width slab of the CSR's row heads: slab[row * width + j] = entries[rowptr[row] + j] for
- * j < min(degree, width), {col = -1, val = 0} beyond.  With it lgc_spmm fetches a short row's entries in
- * the same memory round trip as its row pointer (the address depends on the row id only), which is what
- * bounds the short-row kernel.  width: 8 (W=4: 775, W=16: 879 vs 737 us per hop).
- * slab: lgc_entry [n_rows * width]. */
-int lgc_build_slab(const int32_t *rowptr, const lgc_entry *entries, int64_t n_rows, int32_t width,
-                   lgc_entry *slab, void *stream);
+/* ---------------------------------------------------------------------------------------
+ * Tiled rows: rows with at most 32 entries, listed in a caller-chosen processing order.
+ *
+ * Same arithmetic as lgc_spmm's short rows -- the gather -> scale -> scatter-add of one PyG LGConv layer,
+ * called from src/lightgcn.py:96 (and the epilogue of src/lightgcn.py:93,97) -- for the rows of `order`,
+ * entries in edge order, products rounded before the add.  lgc_build_tiles copies those rows into the tile
+ * layout: 1 KiB pieces (2 KiB for width 32) that one coalesced access per wavefront fetches, holding
+ * 128 / width (width 32: 8) whole rows each, padding entries col = -1 -- the hop reads no row pointer.
+ *   order    int32 [n_slots]: row ids, -1 = empty slot; n_slots a multiple of the rows per tile R
+ *            (16 for width 8, 8 for width 16 and 32); every listed row must have at most `width` entries.
+ *            Slot g * (R/4) + bt of a tile is processed by lane group g in batch bt.
+ *   meta     int32 [n_tiles]: byte bt = the largest entry count among the four rows of batch bt (upper bounds
+ *            are allowed), or NULL.  With meta, a 61..64-wide table and tables below 4 GiB the kernel takes the
+ *            path without divergent control flow (DPP broadcasts, buffer addressing); otherwise a generic one.
+ *   width    8, 16 or 32 entries per row
+ *   parts    1, or 2 (dim a multiple of 8; meant for dim*4 a multiple of 256 bytes, generic path only): the two
+ *            column halves of every row are computed by workgroups on different XCDs, halving the bytes of the
+ *            gathered table each XCD's L2 has to hold
+ *   y[row] = a * sum_k val_k * x[col_k] + b * r[row]   (r may be NULL)
+ */
+int lgc_build_tiles(const int32_t *rowptr, const lgc_entry *entries, const int32_t *order, int64_t n_slots,
+                    int32_t width, lgc_entry *slab, void *stream);
+
+int lgc_spmm_tiles(const int32_t *order, const int32_t *meta, const lgc_entry *slab, int32_t n_tiles, int32_t width,
+                   int32_t tiles_per_wave, int32_t parts, int64_t table_rows, const float *x, int64_t x_stride,
+                   float *y, int64_t y_stride, const float *r, int64_t r_stride, float a, float b, int32_t dim,
+                   void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * One propagation hop:  y[row] = a * sum_k entries[k].val * x[entries[k].col] + b * r[row]
@@ -131,14 +151,11 @@ int lgc_build_slab(const int32_t *rowptr, const lgc_entry *entries, int64_t n_ro
  *   x, y, r     fp32, row strides in floats (>= dim); any dword-aligned rows are accepted, 16-byte
  *               aligned rows (dim % 4 == 0) are the fast case;  y must not alias x
  *   partials    fp32 [n_slots, dim] or NULL when no chunk has slot >= 0
- *   slab, slab_width  from lgc_build_slab, or NULL/0: then short rows read their entries through rowptr.
- *               Used only when a row's lane group has at least slab_width lanes (dim >= 4 * slab_width).
  * ------------------------------------------------------------------------------------- */
 int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries,
              int32_t row_begin, int32_t row_end, int32_t short_max,
              const lgc_chunk *chunks, int32_t n_chunks,
              const lgc_multi_row *multi, int32_t n_multi, float *partials,
-             const lgc_entry *slab, int32_t slab_width,
              int64_t table_rows,
              const float *x, int64_t x_stride,
              float *y, int64_t y_stride,

@@ -64,14 +64,25 @@ def test_error_strings_and_dim_support():
 def test_argument_errors_are_reported_before_any_launch():
     lib = _native.load()
     one = ctypes.c_void_p(16)            # never dereferenced: every call below must fail validation first
-    assert lib.lgc_spmm(one, one, 0, 4, 32, None, 0, None, 0, None, None, 0, 8, one, 64, ctypes.c_void_p(32), 64, None, 0,
+    assert lib.lgc_spmm(one, one, 0, 4, 32, None, 0, None, 0, None, 8, one, 64, ctypes.c_void_p(32), 64, None, 0,
                         1.0, 0.0, 300, None) == -2                                      # LGC_E_DIM
-    assert lib.lgc_spmm(one, one, 0, 4, 32, None, 0, None, 0, None, None, 0, 8, one, 64, one, 64, None, 0,
+    assert lib.lgc_spmm(one, one, 0, 4, 32, None, 0, None, 0, None, 8, one, 64, one, 64, None, 0,
                         1.0, 0.0, 64, None) == -1                                       # y aliases x
-    assert lib.lgc_spmm(one, one, 0, 4, 32, None, 0, None, 0, None, None, 0, 8, ctypes.c_void_p(18), 64, ctypes.c_void_p(32), 64,
+    assert lib.lgc_spmm(one, one, 0, 4, 32, None, 0, None, 0, None, 8, ctypes.c_void_p(18), 64, ctypes.c_void_p(32), 64,
                         None, 0, 1.0, 0.0, 64, None) == -5                              # x not dword-aligned
-    assert lib.lgc_spmm(one, one, 0, 4, 32, None, 3, None, 0, None, None, 0, 8, one, 64, ctypes.c_void_p(32), 64, None, 0,
+    assert lib.lgc_spmm(one, one, 0, 4, 32, None, 3, None, 0, None, 8, one, 64, ctypes.c_void_p(32), 64, None, 0,
                         1.0, 0.0, 64, None) == -1                                       # chunks missing
+    two = ctypes.c_void_p(32)
+    tiles = lambda **kw: lib.lgc_spmm_tiles(one, one, one, kw.get("n", 4), kw.get("w", 8), kw.get("tpw", 1), kw.get("parts", 1),
+                                            100, one, kw.get("xs", 64), kw.get("y", two), 64, None, 0, 1.0, 0.0,
+                                            kw.get("dim", 64), None)
+    assert tiles(dim=300) == -2 and tiles(dim=3) == -2                                    # LGC_E_DIM (tiles need >= 4)
+    assert tiles(w=12) == -1 and tiles(tpw=0) == -1 and tiles(parts=3) == -1 and tiles(y=one) == -1
+    assert tiles(xs=32) == -1 and tiles(n=-1) == -1
+    assert tiles(n=0) == 0                                                                # nothing to do: no launch
+    assert lib.lgc_build_tiles(one, one, one, 15, 8, one, None) == -1                     # not whole tiles
+    assert lib.lgc_build_tiles(one, one, one, 16, 9, one, None) == -1
+    assert lib.lgc_build_tiles(one, one, one, 0, 8, one, None) == 0
     assert lib.lgc_build_csr(one, None, -1, 5, 0, 1, None, one, one, None, one, one, one, 1 << 20, one, None) == -1
     assert lib.lgc_build_csr(one, None, 10, 5, 1, 1, None, one, one, None, one, one, one, 1 << 20, one, None) == -1
     assert lib.lgc_build_csr(one, None, 10, 5, 0, 1, None, one, one, None, one, one, ctypes.c_void_p(256), 8, one,
@@ -261,3 +272,78 @@ def test_algorithmic_bytes_match_baseline_md():
 def test_xavier_table_bound_and_seed():
     w = synth.xavier_table(1000, 64, 3)
     assert w.abs().max() <= (6 / 1064) ** 0.5 and torch.equal(w, synth.xavier_table(1000, 64, 3))
+
+
+# ----------------------------------------------------------------------------------------------
+# tile planner (pure index arithmetic) and saved-graph validation
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["cold", "natural"])
+@pytest.mark.parametrize("max_len", [0, 4, 8, 20, 32, 1000])
+def test_tile_plan_lists_every_short_row_once_in_the_narrowest_class(mode, max_len):
+    from gnn_ecommerce_amd.graph import TILE_WIDTHS, plan_tile_classes, tile_geometry
+    gen = torch.Generator().manual_seed(max_len + 17)
+    n, lo, hi = 700, 37, 655
+    deg = torch.randint(0, 12, (n,), generator=gen)
+    deg[torch.randint(0, n, (40,), generator=gen)] = torch.randint(12, 60, (40,), generator=gen)
+    deg[5], deg[100], deg[101] = 0, 0, 33
+    rowptr = torch.zeros(n + 1, dtype=torch.int32)
+    rowptr[1:] = torch.cumsum(deg, 0)
+    cols = torch.randint(0, 300, (int(rowptr[-1]),), generator=gen, dtype=torch.int32)
+    classes = plan_tile_classes(rowptr, cols, lo, hi, max_len, mode)
+    cap = min(max_len, 32)
+    seen = []
+    prev_width = 0
+    for width, order, meta in classes:
+        assert width in TILE_WIDTHS and width > prev_width and order.dtype == torch.int32 and meta.dtype == torch.int32
+        r_tile, b_tile = tile_geometry(width)
+        assert order.numel() % r_tile == 0 and meta.numel() == order.numel() // r_tile
+        rows = order[order >= 0].long()
+        d = deg[rows]
+        assert ((rows >= lo) & (rows < hi)).all()
+        assert (d <= min(width, cap)).all() and (d > min(prev_width, cap) if prev_width else d >= 0).all()
+        # meta byte bt = the longest of the four rows {slot g * B + bt}
+        tiles = order.view(-1, r_tile).long()
+        dt = torch.where(tiles >= 0, deg[tiles.clamp(min=0)], torch.zeros_like(tiles))
+        for bt in range(b_tile):
+            want = dt[:, [g * b_tile + bt for g in range(4)]].amax(dim=1)
+            assert torch.equal((meta.long() >> (8 * bt)) & 0xFF, want)
+        # batches are ordered longest first inside a tile
+        bmax = torch.stack([(meta.long() >> (8 * bt)) & 0xFF for bt in range(b_tile)], dim=1)
+        assert (bmax[:, 1:] <= bmax[:, :-1]).all()
+        seen.append(rows)
+        prev_width = width
+    seen = torch.cat(seen) if seen else torch.zeros(0, dtype=torch.long)
+    want = torch.nonzero(deg[lo:hi] <= cap).flatten() + lo
+    assert torch.equal(torch.sort(seen).values, want)             # each short row exactly once, nothing else
+
+
+def test_cold_order_puts_rows_sharing_a_rare_column_next_to_each_other():
+    from gnn_ecommerce_amd.graph import plan_tile_classes
+    # 64 rows of 2 entries: column 0 is in every row, the second column is row // 4 + 1 (each used by 4 rows), shuffled
+    perm = torch.randperm(64, generator=torch.Generator().manual_seed(0))
+    second = (perm // 4 + 1).int()
+    cols = torch.stack([torch.zeros(64, dtype=torch.int32), second], dim=1).reshape(-1)
+    rowptr = (2 * torch.arange(65)).int()
+    (width, order, _), = plan_tile_classes(rowptr, cols, 0, 64, 32, "cold")
+    tiles = order.view(-1, 16).long()
+    for t in tiles:                      # a tile of 16 rows = 4 whole groups of rows with the same rare column
+        assert len(set(second[t].tolist())) == 4
+
+
+def test_saved_graph_validation_rejects_tampered_tensors():
+    from gnn_ecommerce_amd import PropGraph
+    rowptr = torch.tensor([0, 2, 3, 5], dtype=torch.int32)
+    entries = torch.tensor([[1, 0], [2, 0], [0, 0], [0, 0], [1, 0]], dtype=torch.int32)
+    deg = dis = torch.ones(3)
+    ok = dict(rowptr=rowptr, entries=entries, deg=deg, dis=dis, num_nodes=3, num_edges=5, split=None, where="t")
+    PropGraph.validate_csr(**ok)
+    bad_col = entries.clone(); bad_col[3, 0] = 3
+    neg_col = entries.clone(); neg_col[0, 0] = -1
+    for change in (dict(rowptr=torch.tensor([0, 3, 2, 5], dtype=torch.int32)),         # not monotone
+                   dict(rowptr=torch.tensor([0, 2, 3, 4], dtype=torch.int32)),         # does not end at num_edges
+                   dict(rowptr=torch.tensor([1, 2, 3, 5], dtype=torch.int32)),         # does not start at 0
+                   dict(rowptr=rowptr[:-1]), dict(rowptr=rowptr.long()),
+                   dict(entries=bad_col), dict(entries=neg_col), dict(entries=entries[:4]),
+                   dict(deg=torch.ones(2)), dict(dis=torch.ones(3, dtype=torch.float64)), dict(split=3), dict(split=0)):
+        with pytest.raises(ValueError):
+            PropGraph.validate_csr(**{**ok, **change})

@@ -552,3 +552,68 @@ def test_end_to_end_caller_loop_learns(device):
     assert log[-1]["bpr"] < log[0]["bpr"] < 0.70
     chance = 20 / 800
     assert log[-1]["R@20"] > 4 * chance and log[-1]["R@20"] >= log[0]["R@20"] - 0.02
+
+
+@pytest.mark.parametrize("dim", [64, 63, 61, 60, 90, 16, 7, 4, 128])
+def test_tiled_rows_are_bit_identical_to_the_row_pointer_path(device, dim, monkeypatch):
+    """lgc_spmm_tiles (processing order, 1 KiB tiles, DPP fast path at 61..64) vs lgc_spmm's plain row part:
+    same entries in the same order, products rounded before the add -> the same bits, with and without epilogue."""
+    from gnn_ecommerce_amd.graph import Operator
+    g, ei, ew = small_graph(21, 3000, 400, 30000)
+    n = g.num_nodes
+    pg = PropGraph(ei.to(device), ew.to(device), n)
+    op = pg.forward_op
+    x = synth.xavier_table(n, dim, 3, device)
+    r = synth.xavier_table(n, dim, 4, device)
+    plain = Operator.build(n, op.rowptr, op.entries, 0, n, 32, 256, tiles=False)
+    assert not plain.tiled
+    want = plain.apply(x, torch.empty_like(x))
+    want_r = plain.apply(x, torch.empty_like(x), a=0.75, r=r, b=0.3)
+    for mode in ("cold", "natural"):
+        monkeypatch.setattr("gnn_ecommerce_amd.graph.TILE_ORDER", mode)
+        tiled = Operator.build(n, op.rowptr, op.entries, 0, n, 32, 256, tiles=True)
+        assert tiled.tiled and {tc.width for tc in tiled.tiles} <= {8, 16, 32}
+        for no_fast in ("", "1"):
+            if no_fast:
+                monkeypatch.setenv("LGCN_NO_FAST_TILES", "1")
+            else:
+                monkeypatch.delenv("LGCN_NO_FAST_TILES", raising=False)
+            got = tiled.apply(x, torch.full_like(x, float("nan")))
+            got_r = tiled.apply(x, torch.full_like(x, float("nan")), a=0.75, r=r, b=0.3)
+            assert torch.equal(got, want) and torch.equal(got_r, want_r), (mode, no_fast)
+    # a strided (padded) table takes the same path
+    wide = torch.zeros((n, dim + 8), device=device)
+    xs, ys = wide[:, :dim], torch.zeros((n, dim + 8), device=device)[:, :dim]
+    xs.copy_(x)
+    assert torch.equal(tiled.apply(xs, ys), want)
+
+
+def test_tampered_saved_graph_is_refused_at_load(device, tmp_path):
+    from safetensors import safe_open
+    from safetensors.torch import save_file
+    g, ei, ew = small_graph(5, 300, 60, 2500)
+    pg = PropGraph(ei.to(device), ew.to(device), g.num_nodes)
+    path = str(tmp_path / "g.safetensors")
+    pg.save(path)
+    with safe_open(path, framework="pt", device="cpu") as f:
+        meta, t = f.metadata(), {k: f.get_tensor(k) for k in f.keys()}
+    assert "slab" not in t
+    bad = dict(t)
+    bad["entries"] = t["entries"].clone()
+    bad["entries"][7, 0] = g.num_nodes + 5                         # a column outside the graph
+    save_file(bad, str(tmp_path / "bad1.safetensors"), metadata=meta)
+    with pytest.raises(ValueError):
+        PropGraph.load(str(tmp_path / "bad1.safetensors"), device)
+    bad = dict(t)
+    bad["rowptr"] = t["rowptr"].clone()
+    bad["rowptr"][3] = bad["rowptr"][2] - 1 if bad["rowptr"][2] > 0 else bad["rowptr"][-1] + 1
+    save_file(bad, str(tmp_path / "bad2.safetensors"), metadata=meta)
+    with pytest.raises(ValueError):
+        PropGraph.load(str(tmp_path / "bad2.safetensors"), device)
+    save_file({k: v for k, v in t.items() if k != "dis"}, str(tmp_path / "bad3.safetensors"), metadata=meta)
+    with pytest.raises(ValueError):
+        PropGraph.load(str(tmp_path / "bad3.safetensors"), device)
+    save_file(t, str(tmp_path / "bad4.safetensors"), metadata={**meta, "num_edges": str(pg.num_edges - 1)})
+    with pytest.raises(ValueError):
+        PropGraph.load(str(tmp_path / "bad4.safetensors"), device)
+    PropGraph.load(path, device)
