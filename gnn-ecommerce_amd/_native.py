@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 from typing import Optional
 
 import torch
@@ -22,6 +22,20 @@ ABI_VERSION = 5
 # status bits (include/lgconv_hip.h)
 ST_INDEX_OOB = 1
 ST_SAMPLER_EXHAUSTED = 2
+
+class SweepCfg(Structure):
+    """lgc_sweep_cfg"""
+    _fields_ = [("n_bands", c_int32), ("waves_per_band_round", c_int32), ("row_cap", c_int32), ("piece_cap", c_int32),
+                ("lookahead", c_int32)]
+
+
+class SweepDims(Structure):
+    """lgc_sweep_dims"""
+    _fields_ = [("n_bands", c_int32), ("rounds", c_int32), ("row_cap", c_int32), ("piece_cap", c_int32),
+                ("n_rows", c_int32), ("reserved", c_int32),
+                ("n_waves", c_int64), ("n_slabs", c_int64), ("n_slots", c_int64), ("n_entries", c_int64),
+                ("n_steps", c_int64), ("n_padding", c_int64)]
+
 
 # symbol -> (restype, argtypes); tests check every name against the header and the .so
 SIGNATURES = {
@@ -37,6 +51,15 @@ SIGNATURES = {
     "lgc_build_tiles": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "lgc_spmm_tiles": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int64, c_void_p, c_int64,
                                c_void_p, c_int64, c_void_p, c_int64, c_float, c_float, c_int32, c_void_p]),
+    "lgc_sweep_plan_create": (c_void_p, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, POINTER(SweepCfg),
+                                         POINTER(c_int)]),
+    "lgc_sweep_plan_dims": (c_int, [c_void_p, POINTER(SweepDims)]),
+    "lgc_sweep_plan_export": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lgc_sweep_plan_free": (None, [c_void_p]),
+    "lgc_sweep_ok": (c_int, [c_int32, c_int64, c_int64]),
+    "lgc_spmm_sweep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int32, c_void_p,
+                               c_int32, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float, c_float,
+                               c_int32, c_void_p]),
     "lgc_lincomb": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p]),
     "lgc_sample_triples": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_uint64,
                                    c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]),

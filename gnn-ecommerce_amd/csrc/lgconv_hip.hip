@@ -23,6 +23,11 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <new>
+#include <thread>
+#include <vector>
 
 #include "lgconv_hip.h"
 
@@ -697,6 +702,113 @@ __global__ __launch_bounds__(kBlock) void k_rows_tile_dpp(TileArgs p) {
     tiles_body_dpp<W, L>(p, blockIdx.x);
 }
 
+
+// ----------------------------------------------------------------------------------------
+// Long rows over a huge gathered table: the band sweep (k_sweep) -- item step of a user|item graph
+// ----------------------------------------------------------------------------------------
+// The item step gathers 10.2 M user rows from a 420 MB table; with one wavefront per chunk of one row every
+// use of a user row (6.2 on average, by unrelated rows at unrelated times on unrelated XCDs) crosses the fabric:
+// 2.75 GB per hop at the fabric's ~7 TB/s, although the same kernel runs in 180 us when the gathers hit L2
+// (tools/exp_floor.py).  Here the columns are cut into 8 bands = XCDs (blockIdx % 8), every (row, band) pair is a
+// PIECE with an accumulator in LDS, and all wavefronts of a band walk its columns in ascending order at the same
+// pace, so a table row is fetched from memory by the first wave that needs it and found in that XCD's L2 by the
+// others.  LDS holds 16 x 39 accumulators per CU, a band has ~56 k pieces: three rounds.
+//   * a wave owns up to `row_cap` pieces and one merged, column-sorted entry list over all of them, cut into STEPS
+//     of four entries (one per 16-lane group) that the planner keeps free of two entries for the same piece, so the
+//     four read-modify-writes of a step never touch the same LDS row; entry = {col : 24 | piece : 8, val};
+//   * 32 steps = one 1 KiB slab, fetched by one coalesced dwordx4 per lane; lane 16 g + q holds steps 2q, 2q+1 of
+//     group g, handed to the group's lanes with DPP row_newbcast; gathers go through a buffer descriptor, padding
+//     entries (col = 0xFFFFFF, out of range: zeros) update a dummy LDS row;
+//   * at the end a wave writes its pieces to their partial slots (contiguous per output row, band-major) and
+//     k_spmm_combine adds a row's slots in that fixed order: deterministic, no float atomics.
+struct SweepArgs {
+    const u4 *slabs;               // [n_slabs * 64]
+    const int32_t *wave_slab_ptr;  // [n_waves + 1]
+    const int32_t *wave_npieces;   // [n_waves]
+    const int32_t *piece_slot;     // [n_waves * row_cap]
+    const float *x;
+    float *partials;               // [n_slots, dim]
+    int64_t x_stride;
+    uint32_t x_bytes;
+    int32_t dim, row_cap, n_waves, wave_begin;
+};
+
+template <int Q, int HALF>
+__device__ __forceinline__ void sweep_fetch(const u4 &cur, int &packed, int &valbits) {
+    packed = bcast16<Q>((int)(HALF ? cur.z : cur.x));
+    valbits = bcast16<Q>((int)(HALF ? cur.w : cur.y));
+}
+
+template <int DEPTH>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, DEPTH == 16 ? 4 : 8))) void k_sweep(SweepArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wib = threadIdx.x / kWave;
+    const int w = __builtin_amdgcn_readfirstlane((int)(p.wave_begin + blockIdx.x * (kBlock / kWave) + wib));
+    if (w >= p.n_waves) return;
+    const int npieces = p.wave_npieces[w];
+    if (npieces == 0) return;  // wave-uniform
+    const int l = lane & 15, g = lane >> 4;
+    const int c0 = min(l * 4, p.dim - 4);
+    float *acc = lds + (size_t)wib * (p.row_cap + 1) * 64;     // rows of 64 floats, row `row_cap` = dummy
+    {   // zero my region: (row_cap + 1) * 256 B, 1 KiB per wave-instruction
+        const f4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int i = lane; i < (p.row_cap + 1) * 16; i += kWave) *reinterpret_cast<f4 *>(acc + i * 4) = z;
+    }
+    const auto xsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, p.x_bytes, 0x00020000);
+    const unsigned xs = (unsigned)p.x_stride * 4u, xoff = (unsigned)c0 * 4u;
+    float *mine = acc + l * 4;                                  // + piece * 64
+    int slab = p.wave_slab_ptr[w];
+    const int slab_end = p.wave_slab_ptr[w + 1];
+    if (slab >= slab_end) return;
+    u4 nxt = p.slabs[(int64_t)slab * kWave + lane];
+    for (; slab < slab_end; ++slab) {
+        const u4 cur = nxt;
+        if (slab + 1 < slab_end) nxt = p.slabs[(int64_t)(slab + 1) * kWave + lane];
+        // 32 steps, DEPTH gathers in flight: issue step s + DEPTH after consuming step s
+        f4 xv[DEPTH];
+        int pk[DEPTH], vb[DEPTH];
+#define LGC_ISSUE(S)                                                                                                   \
+    {                                                                                                                  \
+        sweep_fetch<((S) >> 1), ((S) & 1)>(cur, pk[(S) % DEPTH], vb[(S) % DEPTH]);                                     \
+        xv[(S) % DEPTH] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(                                \
+            xsrc, __umul24(pk[(S) % DEPTH] & 0xFFFFFF, xs) + xoff, 0, 0));                                             \
+    }
+#define LGC_CONSUME(S)                                                                                                 \
+    {                                                                                                                  \
+        float *row = mine + ((unsigned)pk[(S) % DEPTH] >> 24) * 64;                                                    \
+        f4 a = *reinterpret_cast<f4 *>(row);                                                                           \
+        const float v = __int_as_float(vb[(S) % DEPTH]);                                                               \
+        const f2 v2 = {v, v};                                                                                          \
+        const f2 lo = {xv[(S) % DEPTH].x, xv[(S) % DEPTH].y}, hi = {xv[(S) % DEPTH].z, xv[(S) % DEPTH].w};             \
+        const f2 alo = f2{a.x, a.y} + lo * v2, ahi = f2{a.z, a.w} + hi * v2;                                           \
+        *reinterpret_cast<f4 *>(row) = f4{alo.x, alo.y, ahi.x, ahi.y};                                                 \
+    }
+#define LGC_STEP(S)                                                                                                    \
+    LGC_CONSUME(S)                                                                                                     \
+    if constexpr ((S) + DEPTH < 32) LGC_ISSUE((S) + DEPTH)
+        LGC_ISSUE(0) LGC_ISSUE(1) LGC_ISSUE(2) LGC_ISSUE(3) LGC_ISSUE(4) LGC_ISSUE(5) LGC_ISSUE(6) LGC_ISSUE(7)
+        if constexpr (DEPTH == 16) {
+            LGC_ISSUE(8) LGC_ISSUE(9) LGC_ISSUE(10) LGC_ISSUE(11) LGC_ISSUE(12) LGC_ISSUE(13) LGC_ISSUE(14) LGC_ISSUE(15)
+        }
+        LGC_STEP(0) LGC_STEP(1) LGC_STEP(2) LGC_STEP(3) LGC_STEP(4) LGC_STEP(5) LGC_STEP(6) LGC_STEP(7)
+        LGC_STEP(8) LGC_STEP(9) LGC_STEP(10) LGC_STEP(11) LGC_STEP(12) LGC_STEP(13) LGC_STEP(14) LGC_STEP(15)
+        LGC_STEP(16) LGC_STEP(17) LGC_STEP(18) LGC_STEP(19) LGC_STEP(20) LGC_STEP(21) LGC_STEP(22) LGC_STEP(23)
+        LGC_STEP(24) LGC_STEP(25) LGC_STEP(26) LGC_STEP(27) LGC_STEP(28) LGC_STEP(29) LGC_STEP(30) LGC_STEP(31)
+#undef LGC_STEP
+#undef LGC_CONSUME
+#undef LGC_ISSUE
+    }
+    // write my pieces to their partial slots: lane group g takes pieces g, g + 4, ...
+    const int32_t *slots = p.piece_slot + (int64_t)w * p.row_cap;
+    for (int pc = g; pc < npieces; pc += 4) {
+        const f4 a = *reinterpret_cast<const f4 *>(mine + pc * 64);
+        Acc<4> o;
+        o.v[0] = a.x; o.v[1] = a.y; o.v[2] = a.z; o.v[3] = a.w;
+        store_row<4>(p.partials + (int64_t)slots[pc] * p.dim + c0, o);
+    }
+}
+
 // order + CSR -> tile layout: piece ((t*L + k)*R + s)*PPR + q holds entries k*Wk + 2q, +1 of the row in slot s of tile t
 __global__ void k_build_tiles(const int32_t *__restrict__ rowptr, const lgc_entry *__restrict__ entries,
                               const int32_t *__restrict__ order, int64_t n_slots, int32_t W, int32_t L,
@@ -720,6 +832,97 @@ __global__ void k_build_tiles(const int32_t *__restrict__ rowptr, const lgc_entr
         if (b + j < e) v = entries[b + j];
     }
     slab[i] = v;
+}
+
+
+// Sum of a swept row's partial slots + epilogue, one launch:
+//   blocks [0, n_wide)   rows cut into many pieces (hubs): one WORKGROUP per row -- unit (wave, lane group) u of 16
+//                        adds slots u, u + 16, ... (4 loads in flight), then groups are added in order inside the
+//                        wave (shuffles) and waves in order through LDS: a fixed association;
+//   the other blocks     rows with a handful of slots (one per band): one LANE GROUP per row, slots in order --
+//                        four rows per wavefront at D=64.
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_sweep_combine(SpmmArgs p, const lgc_multi_row *__restrict__ wide, int32_t n_wide,
+                                                         const lgc_multi_row *__restrict__ multi, int32_t n_multi,
+                                                         const float *__restrict__ partials) {
+    __shared__ float wave_sum[(kBlock / kWave) * 256];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wv = threadIdx.x / kWave;
+    const int groups = kWave / p.lpr;
+    const int g = lane / p.lpr;
+    const int l = lane - g * p.lpr;
+    const int c0 = lane_column<VEC>(l, p.dim);
+    const float *pb = partials + c0;
+    if ((int32_t)blockIdx.x < n_wide) {
+        const lgc_multi_row mr = wide[blockIdx.x];
+        const bool active = g < groups;
+        const int units = (kBlock / kWave) * groups;
+        Acc<VEC> acc;
+        acc.zero();
+        if (active) {
+            int32_t s = mr.slot_begin + wv * groups + g;
+            for (; s + 3 * units < mr.slot_end; s += 4 * units) {
+                Acc<VEC> t0 = load_row<VEC>(pb + (int64_t)s * p.dim);
+                Acc<VEC> t1 = load_row<VEC>(pb + (int64_t)(s + units) * p.dim);
+                Acc<VEC> t2 = load_row<VEC>(pb + (int64_t)(s + 2 * units) * p.dim);
+                Acc<VEC> t3 = load_row<VEC>(pb + (int64_t)(s + 3 * units) * p.dim);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i)
+                    acc.v[i] = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(acc.v[i], t0.v[i]), t1.v[i]), t2.v[i]), t3.v[i]);
+            }
+            for (; s < mr.slot_end; s += units) {
+                Acc<VEC> t0 = load_row<VEC>(pb + (int64_t)s * p.dim);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc.v[i] = __fadd_rn(acc.v[i], t0.v[i]);
+            }
+        }
+        for (int j = 1; j < groups; ++j) {   // every lane executes the shuffles; group 0 keeps the wave's sum
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float other = __shfl_down(acc.v[i], j * p.lpr);
+                if (g == 0) acc.v[i] = __fadd_rn(acc.v[i], other);
+            }
+        }
+        if (active && g == 0) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) wave_sum[wv * 256 + l * VEC + i] = acc.v[i];
+        }
+        __syncthreads();
+        if (wv == 0 && active && g == 0) {
+            for (int o = 1; o < kBlock / kWave; ++o) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc.v[i] = __fadd_rn(acc.v[i], wave_sum[o * 256 + l * VEC + i]);
+            }
+            Acc<VEC> rv;
+            rv.zero();
+            if (p.r != nullptr) rv = load_row<VEC>(p.r + (int64_t)mr.row * p.r_stride + c0);
+            finish_row<VEC, SpmmArgs>(p, mr.row, c0, acc, rv);
+        }
+        return;
+    }
+    const int64_t m = (((int64_t)blockIdx.x - n_wide) * (kBlock / kWave) + wv) * groups + g;
+    if (g >= groups || m >= n_multi) return;
+    const lgc_multi_row mr = multi[m];
+    Acc<VEC> acc, rv;
+    acc.zero();
+    rv.zero();
+    if (p.r != nullptr) rv = load_row<VEC>(p.r + (int64_t)mr.row * p.r_stride + c0);
+    int32_t s = mr.slot_begin;
+    for (; s + 4 <= mr.slot_end; s += 4) {
+        Acc<VEC> t0 = load_row<VEC>(pb + (int64_t)s * p.dim);
+        Acc<VEC> t1 = load_row<VEC>(pb + (int64_t)(s + 1) * p.dim);
+        Acc<VEC> t2 = load_row<VEC>(pb + (int64_t)(s + 2) * p.dim);
+        Acc<VEC> t3 = load_row<VEC>(pb + (int64_t)(s + 3) * p.dim);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i)
+            acc.v[i] = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(acc.v[i], t0.v[i]), t1.v[i]), t2.v[i]), t3.v[i]);
+    }
+    for (; s < mr.slot_end; ++s) {
+        Acc<VEC> t0 = load_row<VEC>(pb + (int64_t)s * p.dim);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc.v[i] = __fadd_rn(acc.v[i], t0.v[i]);
+    }
+    finish_row<VEC, SpmmArgs>(p, mr.row, c0, acc, rv);
 }
 
 struct LincombArgs {
@@ -859,6 +1062,228 @@ int dispatch_dim(const DimCfg &cfg, F &&f) {
 }
 
 bool aligned_to(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+}  // namespace
+
+
+// ----------------------------------------------------------------------------------------
+// Band-sweep planner (host code, host pointers): see k_sweep
+// ----------------------------------------------------------------------------------------
+struct lgc_sweep_plan {
+    lgc_sweep_dims dims{};
+    std::vector<uint32_t> slabs;          // n_slabs * 256 dwords
+    std::vector<int32_t> wave_slab_ptr;   // n_waves + 1
+    std::vector<int32_t> wave_npieces;    // n_waves
+    std::vector<int32_t> piece_slot;      // n_waves * row_cap
+    std::vector<lgc_multi_row> multi;     // one per row of the range
+};
+
+namespace {
+
+struct SweepPiece {
+    int32_t begin, count;   // into the column-sorted entry array
+    int32_t band;
+};
+
+template <class F>
+void parallel_for(int64_t n, F &&f) {
+    unsigned nt = std::thread::hardware_concurrency();
+    if (const char *e = getenv("LGCN_PLAN_THREADS")) nt = (unsigned)atoi(e);
+    nt = std::max(1u, std::min(nt, 32u));
+    if (nt == 1 || n < 64) {
+        f(0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const int64_t per = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; ++t) {
+        const int64_t lo = t * per, hi = std::min<int64_t>(n, lo + per);
+        if (lo < hi) th.emplace_back([&f, lo, hi] { f(lo, hi); });
+    }
+    for (auto &t : th) t.join();
+}
+
+int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin, int32_t row_end,
+                     int32_t col_lo, int32_t col_hi, const lgc_sweep_cfg &cfg) {
+    const int NB = cfg.n_bands, WPBR = cfg.waves_per_band_round, CAP = cfg.row_cap;
+    const int64_t e0 = rowptr[row_begin], e1 = rowptr[row_end];
+    const int64_t ne = e1 - e0;
+    const int32_t n_rows = row_end - row_begin;
+    // A. bands: column ranges with (nearly) equal entry counts
+    std::vector<int32_t> hist((size_t)(col_hi - col_lo) + 1, 0);
+    for (int64_t k = e0; k < e1; ++k) {
+        const int32_t c = entries[k].col;
+        if (c < col_lo || c >= col_hi) return LGC_E_INVAL;
+        ++hist[c - col_lo];
+    }
+    std::vector<int32_t> bound(NB + 1, col_hi);   // band b = columns [bound[b], bound[b+1])
+    bound[0] = col_lo;
+    {
+        int64_t run = 0;
+        int b = 1;
+        for (int32_t c = 0; c < col_hi - col_lo && b < NB; ++c) {
+            run += hist[c];
+            while (b < NB && run * NB >= ne * b && ne > 0) bound[b++] = col_lo + c + 1;
+        }
+    }
+    // B. every row sorted by column (stable: equal columns keep edge order); run length of each (row, band)
+    std::vector<lgc_entry> sorted((size_t)ne);
+    std::vector<int32_t> run_len((size_t)n_rows * NB, 0);
+    parallel_for(n_rows, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) {
+            const int64_t s = rowptr[row_begin + i] - e0, e = rowptr[row_begin + i + 1] - e0;
+            std::copy(entries + e0 + s, entries + e0 + e, sorted.begin() + s);
+            std::stable_sort(sorted.begin() + s, sorted.begin() + e,
+                             [](const lgc_entry &a, const lgc_entry &b) { return a.col < b.col; });
+            int64_t k = s;
+            for (int b = 0; b < NB && k < e; ++b) {
+                int64_t k2 = k;
+                while (k2 < e && sorted[(size_t)k2].col < bound[b + 1]) ++k2;
+                run_len[(size_t)i * NB + b] = (int32_t)(k2 - k);
+                k = k2;
+            }
+        }
+    });
+    // piece length cap: the configured one, raised in steps of 16 while a longer cap saves a whole round
+    auto rounds_for = [&](int64_t pcap) {
+        std::vector<int64_t> per_band((size_t)NB, 0);
+        for (int64_t i = 0; i < n_rows; ++i)
+            for (int b = 0; b < NB; ++b) per_band[(size_t)b] += (run_len[(size_t)i * NB + b] + pcap - 1) / pcap;
+        const int64_t most = *std::max_element(per_band.begin(), per_band.end());
+        return (int)std::max<int64_t>(1, (most + (int64_t)WPBR * CAP - 1) / ((int64_t)WPBR * CAP));
+    };
+    int PCAP = cfg.piece_cap;
+    const int fewest = rounds_for(int64_t(1) << 40);
+    while (PCAP < 4 * cfg.piece_cap && rounds_for(PCAP) > fewest) PCAP += 16;
+    const int rounds = rounds_for(PCAP);
+    // pieces: long runs cut into near-equal parts of <= PCAP entries; slots are contiguous per row, band-major
+    std::vector<SweepPiece> pieces;
+    pieces.reserve((size_t)n_rows * NB + 1024);
+    pl.multi.resize((size_t)n_rows);
+    for (int64_t i = 0; i < n_rows; ++i) {
+        lgc_multi_row &mr = pl.multi[(size_t)i];
+        mr.row = row_begin + (int32_t)i;
+        mr.slot_begin = (int32_t)pieces.size();
+        mr.reserved = 0;
+        int64_t k = rowptr[row_begin + i] - e0;
+        for (int b = 0; b < NB; ++b) {
+            const int64_t cnt = run_len[(size_t)i * NB + b];
+            if (cnt > 0) {
+                const int64_t parts = (cnt + PCAP - 1) / PCAP, per = (cnt + parts - 1) / parts;
+                for (int64_t q = 0; q < cnt; q += per)
+                    pieces.push_back({(int32_t)(k + q), (int32_t)std::min<int64_t>(per, cnt - q), b});
+            }
+            k += cnt;
+        }
+        mr.slot_end = (int32_t)pieces.size();
+    }
+    const int64_t n_pieces = (int64_t)pieces.size();
+    // C. pieces -> waves, band by band: heaviest first, dealt out in serpentine order (equal piece counts, close loads)
+    std::vector<std::vector<int32_t>> by_band((size_t)NB);
+    for (int64_t i = 0; i < n_pieces; ++i) by_band[(size_t)pieces[(size_t)i].band].push_back((int32_t)i);
+    const int64_t U = (int64_t)rounds * WPBR;           // waves per band
+    const int64_t n_waves = U * NB;
+    std::vector<std::vector<int32_t>> wave_pieces((size_t)n_waves);
+    for (int b = 0; b < NB; ++b) {
+        auto &v = by_band[(size_t)b];
+        std::stable_sort(v.begin(), v.end(), [&](int32_t a, int32_t c) { return pieces[(size_t)a].count > pieces[(size_t)c].count; });
+        for (size_t k = 0; k < v.size(); ++k) {
+            const int64_t lap = (int64_t)(k / (size_t)U), pos = (int64_t)(k % (size_t)U);
+            const int64_t u = (lap & 1) ? (U - 1 - pos) : pos;
+            const int64_t r = u / WPBR, j = u % WPBR;
+            const int64_t w = ((r * (WPBR / 4) + j / 4) * NB + b) * 4 + (j % 4);   // block = (r, j / 4, band), band = block % NB
+            wave_pieces[(size_t)w].push_back(v[k]);
+        }
+    }
+    for (auto &wp : wave_pieces)
+        if ((int)wp.size() > CAP) return LGC_E_INVAL;   // cannot happen: ceil(n / U) <= CAP
+    // D. per wave: merged column-sorted list -> conflict-free steps of 4 -> slabs of 32 steps
+    const uint32_t PAD_X = 0x00FFFFFFu | ((uint32_t)CAP << 24);    // out-of-range column, dummy accumulator row
+    std::vector<std::vector<uint32_t>> wave_slabs((size_t)n_waves);
+    std::vector<int64_t> wave_steps((size_t)n_waves, 0), wave_pad((size_t)n_waves, 0);
+    pl.wave_npieces.assign((size_t)n_waves, 0);
+    pl.piece_slot.assign((size_t)n_waves * CAP, 0);
+    parallel_for(n_waves, [&](int64_t wlo, int64_t whi) {
+        struct Item { int32_t col; float val; int32_t piece; };
+        std::vector<Item> items;
+        std::vector<char> done;
+        for (int64_t w = wlo; w < whi; ++w) {
+            auto &wp = wave_pieces[(size_t)w];
+            auto &out = wave_slabs[(size_t)w];
+            pl.wave_npieces[(size_t)w] = (int32_t)wp.size();
+            items.clear();
+            for (size_t lp = 0; lp < wp.size(); ++lp) {
+                const SweepPiece &pc = pieces[(size_t)wp[lp]];
+                pl.piece_slot[(size_t)w * CAP + lp] = wp[lp];
+                for (int32_t k = 0; k < pc.count; ++k)
+                    items.push_back({sorted[(size_t)(pc.begin + k)].col, sorted[(size_t)(pc.begin + k)].val, (int32_t)lp});
+            }
+            std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.col < b.col; });
+            done.assign(items.size(), 0);
+            size_t head = 0;
+            int64_t step = 0, pad = 0;
+            while (true) {
+                while (head < items.size() && done[head]) ++head;
+                if (head >= items.size()) break;
+                if (step % 32 == 0) {
+                    const size_t base = out.size();
+                    out.resize(base + 256);
+                    for (int i = 0; i < 128; ++i) { out[base + 2 * i] = PAD_X; out[base + 2 * i + 1] = 0u; }
+                }
+                int used[4], n_used = 0, seen = 0;
+                for (size_t i = head; n_used < 4 && i < items.size() && seen < cfg.lookahead; ++i) {
+                    if (done[i]) continue;
+                    ++seen;
+                    bool clash = false;
+                    for (int q = 0; q < n_used; ++q) clash |= used[q] == items[i].piece;
+                    if (clash) continue;
+                    const int grp = n_used;
+                    used[n_used++] = items[i].piece;
+                    done[i] = 1;
+                    const int sl = (int)(step % 32);
+                    // lane 16 g + (s >> 1), component pair (s & 1): dword (16 g + (s >> 1)) * 4 + 2 (s & 1) of the slab
+                    const size_t at = (out.size() - 256) + (size_t)((16 * grp + (sl >> 1)) * 4 + 2 * (sl & 1));
+                    uint32_t vbits;
+                    memcpy(&vbits, &items[i].val, 4);
+                    out[at] = ((uint32_t)items[i].col & 0xFFFFFFu) | ((uint32_t)items[i].piece << 24);
+                    out[at + 1] = vbits;
+                }
+                pad += 4 - n_used;
+                ++step;
+            }
+            wave_steps[(size_t)w] = step;
+            wave_pad[(size_t)w] = pad;
+        }
+    });
+    pl.wave_slab_ptr.assign((size_t)n_waves + 1, 0);
+    int64_t total = 0, n_steps_total = 0, n_pad = 0;
+    for (int64_t w = 0; w < n_waves; ++w) {
+        pl.wave_slab_ptr[(size_t)w] = (int32_t)(total / 256);
+        total += (int64_t)wave_slabs[(size_t)w].size();
+        n_steps_total += wave_steps[(size_t)w];
+        n_pad += wave_pad[(size_t)w];
+    }
+    if (total / 256 >= INT32_MAX) return LGC_E_RANGE;
+    pl.wave_slab_ptr[(size_t)n_waves] = (int32_t)(total / 256);
+    pl.slabs.resize((size_t)total);
+    parallel_for(n_waves, [&](int64_t wlo, int64_t whi) {
+        for (int64_t w = wlo; w < whi; ++w)
+            std::copy(wave_slabs[(size_t)w].begin(), wave_slabs[(size_t)w].end(),
+                      pl.slabs.begin() + (size_t)pl.wave_slab_ptr[(size_t)w] * 256);
+    });
+    pl.dims.n_bands = NB;
+    pl.dims.rounds = rounds;
+    pl.dims.row_cap = CAP;
+    pl.dims.piece_cap = PCAP;
+    pl.dims.n_waves = n_waves;
+    pl.dims.n_slabs = total / 256;
+    pl.dims.n_slots = n_pieces;
+    pl.dims.n_rows = n_rows;
+    pl.dims.n_entries = ne;
+    pl.dims.n_steps = n_steps_total;
+    pl.dims.n_padding = n_pad;
+    return 0;
+}
 
 }  // namespace
 
@@ -1040,6 +1465,107 @@ int lgc_spmm_tiles(const int32_t *order, const int32_t *meta, const lgc_entry *s
     if (width == 8) hipLaunchKernelGGL((k_rows_tile<8, 1>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, p);
     else if (width == 16) hipLaunchKernelGGL((k_rows_tile<16, 1>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, p);
     else hipLaunchKernelGGL((k_rows_tile<32, 2>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, p);
+    return (int)hipGetLastError();
+}
+
+lgc_sweep_plan *lgc_sweep_plan_create(const int32_t *rowptr_host, const lgc_entry *entries_host, int32_t row_begin,
+                                      int32_t row_end, int32_t col_lo, int32_t col_hi, const lgc_sweep_cfg *cfg, int *code) {
+    int rc = LGC_E_INVAL;
+    lgc_sweep_plan *pl = nullptr;
+    if (rowptr_host && (entries_host || rowptr_host[row_end] == rowptr_host[row_begin]) && cfg && row_begin >= 0 &&
+        row_end >= row_begin && col_lo >= 0 && col_hi > col_lo && col_hi <= 0xFFFFFF && cfg->n_bands >= 1 &&
+        cfg->n_bands <= 64 && cfg->waves_per_band_round >= 4 && cfg->waves_per_band_round % 4 == 0 && cfg->row_cap >= 1 &&
+        cfg->row_cap <= 254 && cfg->piece_cap >= 1 && cfg->lookahead >= 4) {
+        pl = new (std::nothrow) lgc_sweep_plan();
+        if (pl) {
+            try {
+                rc = sweep_plan_build(*pl, rowptr_host, entries_host, row_begin, row_end, col_lo, col_hi, *cfg);
+            } catch (const std::bad_alloc &) {
+                rc = (int)hipErrorOutOfMemory;
+            }
+            if (rc != 0) { delete pl; pl = nullptr; }
+        } else {
+            rc = (int)hipErrorOutOfMemory;
+        }
+    }
+    if (code) *code = rc;
+    return pl;
+}
+
+int lgc_sweep_plan_dims(const lgc_sweep_plan *plan, lgc_sweep_dims *dims) {
+    if (!plan || !dims) return LGC_E_INVAL;
+    *dims = plan->dims;
+    return 0;
+}
+
+int lgc_sweep_plan_export(const lgc_sweep_plan *plan, uint32_t *slabs, int32_t *wave_slab_ptr, int32_t *wave_npieces,
+                          int32_t *piece_slot, lgc_multi_row *multi) {
+    if (!plan || !slabs || !wave_slab_ptr || !wave_npieces || !piece_slot || !multi) return LGC_E_INVAL;
+    std::copy(plan->slabs.begin(), plan->slabs.end(), slabs);
+    std::copy(plan->wave_slab_ptr.begin(), plan->wave_slab_ptr.end(), wave_slab_ptr);
+    std::copy(plan->wave_npieces.begin(), plan->wave_npieces.end(), wave_npieces);
+    std::copy(plan->piece_slot.begin(), plan->piece_slot.end(), piece_slot);
+    std::copy(plan->multi.begin(), plan->multi.end(), multi);
+    return 0;
+}
+
+void lgc_sweep_plan_free(lgc_sweep_plan *plan) { delete plan; }
+
+int lgc_sweep_ok(int32_t dim, int64_t table_rows, int64_t x_stride) {
+    if (dim < 61 || dim > 64 || table_rows <= 0 || table_rows >= 0xFFFFFF || x_stride < dim) return 0;
+    const int64_t bytes = ((table_rows - 1) * x_stride + dim) * 4;
+    const uint32_t pad = (uint32_t)(0xFFFFFFull * (uint64_t)(x_stride * 4));
+    return (x_stride * 4 < (1 << 24) && bytes < (int64_t(1) << 32) && (int64_t)pad >= bytes) ? 1 : 0;
+}
+
+int lgc_spmm_sweep(const uint32_t *slabs, const int32_t *wave_slab_ptr, const int32_t *wave_npieces, const int32_t *piece_slot,
+                   int64_t n_waves, int32_t row_cap, const lgc_multi_row *multi, int32_t n_rows,
+                   const lgc_multi_row *multi_wide, int32_t n_wide, float *partials,
+                   int64_t table_rows, const float *x, int64_t x_stride, float *y, int64_t y_stride, const float *r,
+                   int64_t r_stride, float a, float b, int32_t dim, void *stream_) {
+    if (!slabs || !wave_slab_ptr || !wave_npieces || !piece_slot || !partials || !x || !y || n_waves < 0 ||
+        n_waves % 4 != 0 || n_rows < 0 || n_wide < 0 || (n_rows > 0 && !multi) || (n_wide > 0 && !multi_wide) || row_cap < 1 ||
+        row_cap > 254 || x == y)
+        return LGC_E_INVAL;
+    if (!lgc_sweep_ok(dim, table_rows, x_stride)) return LGC_E_DIM;
+    if (y_stride < dim || (r && r_stride < dim)) return LGC_E_INVAL;
+    if (!aligned_to(x, 4) || !aligned_to(y, 4) || (r && !aligned_to(r, 4)) || !aligned_to(slabs, 16) || !aligned_to(partials, 16))
+        return LGC_E_ALIGN;
+    hipStream_t stream = as_stream(stream_);
+    const size_t lds = (size_t)(kBlock / kWave) * (size_t)(row_cap + 1) * 64 * sizeof(float);
+    if (lds > 160 * 1024) return LGC_E_INVAL;
+    if (n_waves > 0) {
+        SweepArgs p{reinterpret_cast<const u4 *>(slabs), wave_slab_ptr, wave_npieces, piece_slot, x, partials, x_stride,
+                    (uint32_t)(((table_rows - 1) * x_stride + dim) * 4), dim, row_cap, (int32_t)n_waves, 0};
+        static bool attr_set = false;
+        if (!attr_set) {   // more than 64 KiB of dynamic LDS needs the opt-in once per process
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               160 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        const char *env_d = getenv("LGCN_SWEEP_DEPTH"), *env_r = getenv("LGCN_SWEEP_LAUNCH_WAVES");
+        const int depth = env_d ? atoi(env_d) : 8;
+        const int64_t per_launch = env_r && atoll(env_r) > 0 ? (atoll(env_r) / 4) * 4 : n_waves;
+        for (int64_t w0 = 0; w0 < n_waves; w0 += per_launch) {
+            p.wave_begin = (int32_t)w0;
+            const unsigned blocks = (unsigned)(std::min<int64_t>(per_launch, n_waves - w0) / 4);
+            if (depth == 16) hipLaunchKernelGGL(k_sweep<16>, dim3(blocks), dim3(kBlock), lds, stream, p);
+            else hipLaunchKernelGGL(k_sweep<8>, dim3(blocks), dim3(kBlock), lds, stream, p);
+        }
+    }
+    DimCfg cfg;
+    dim_cfg(dim, &cfg);
+    SpmmArgs sp{nullptr, nullptr, x, y, r, x_stride, y_stride, r_stride, a, b, dim, cfg.lpr, 0, 0, 0, 0};
+    sp.wt_store = (table_rows * y_stride * 4 < (int64_t(1) << 32)) ? 1 : 0;
+    if (n_wide + n_rows > 0) {
+        const int rows_per_block = (kBlock / kWave) * (kWave / cfg.lpr);
+        hipLaunchKernelGGL((k_sweep_combine<4>), dim3(n_wide + ceil_div(n_rows, rows_per_block)), dim3(kBlock), 0, stream, sp,
+                           multi_wide, n_wide, multi, n_rows, partials);
+    }
     return (int)hipGetLastError();
 }
 

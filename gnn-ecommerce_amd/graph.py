@@ -39,6 +39,16 @@ TILES_PER_WAVE = int(os.environ.get("LGCN_TILES_PER_WAVE", "1"))      # 1 ~ 2 > 
 # share a rarely used table row run close together in time and that row crosses the fabric about once
 # (an LRU model of one 4 MiB L2 gives 47 % -> 63 % hits on the user step); "natural": row order.
 TILE_ORDER = os.environ.get("LGCN_TILE_ORDER", "cold")
+# Band sweep for the long rows of a bipartite half whose gathered table is far larger than the caches (the item
+# step): "auto" = when the half has at least SWEEP_MIN_ENTRIES entries, "1" = whenever the table qualifies, "0" = never.
+USE_SWEEP = os.environ.get("LGCN_SWEEP", "auto")
+SWEEP_MIN_ENTRIES = int(os.environ.get("LGCN_SWEEP_MIN_ENTRIES", "2000000"))
+# 8 wavefronts per CU with 78 accumulators each beat 16 x 39 (44 % vs 20 % L2 hits on the item step: fewer, longer
+# lists keep the wavefronts of a band closer together); 160 KiB of LDS per CU either way.
+SWEEP_CFG = dict(n_bands=8, waves_per_band_round=int(os.environ.get("LGCN_SWEEP_WAVES", "256")),
+                 row_cap=int(os.environ.get("LGCN_SWEEP_ROW_CAP", "78")),
+                 piece_cap=int(os.environ.get("LGCN_SWEEP_PIECE_CAP", "64")),
+                 lookahead=int(os.environ.get("LGCN_SWEEP_LOOKAHEAD", "64")))
 
 
 @dataclass
@@ -186,6 +196,73 @@ def build_tile_classes(rowptr: Tensor, entries: Tensor, row_begin: int, row_end:
     return classes
 
 
+def sweep_plan_host(rowptr: Tensor, entries: Tensor, row_begin: int, row_end: int, col_lo: int, col_hi: int,
+                    cfg: Optional[dict] = None) -> Tuple[dict, Dict[str, Tensor]]:
+    """Run the host planner (lgc_sweep_plan_*) on rows [row_begin, row_end) of a CSR given as tensors on any device;
+    returns (dims, CPU arrays).  Host-only code: callable without a GPU (the CPU tests decode the plan)."""
+    import ctypes
+    lib = _native.load()
+    cfg = dict(SWEEP_CFG, **(cfg or {}))
+    rp = rowptr[row_begin:row_end + 1].to(torch.int64)
+    e0, e1 = int(rp[0]), int(rp[-1])
+    rp_host = (rp - e0).to(torch.int32).cpu().contiguous()
+    ent_host = entries[e0:e1].cpu().contiguous()
+    c_cfg = _native.SweepCfg(**cfg)
+    code = ctypes.c_int(0)
+    handle = lib.lgc_sweep_plan_create(rp_host.data_ptr(), ent_host.data_ptr() if e1 > e0 else None, 0,
+                                       row_end - row_begin, col_lo, col_hi, ctypes.byref(c_cfg), ctypes.byref(code))
+    if not handle:
+        _native.check(code.value or -1, "lgc_sweep_plan_create")
+    try:
+        d = _native.SweepDims()
+        _native.check(lib.lgc_sweep_plan_dims(handle, ctypes.byref(d)), "lgc_sweep_plan_dims")
+        dims = {k: getattr(d, k) for k, _ in _native.SweepDims._fields_}
+        arrays = {"slabs": torch.empty(max(d.n_slabs, 1) * 256, dtype=torch.int32),
+                  "wave_slab_ptr": torch.empty(d.n_waves + 1, dtype=torch.int32),
+                  "wave_npieces": torch.empty(max(d.n_waves, 1), dtype=torch.int32),
+                  "piece_slot": torch.empty(max(d.n_waves * d.row_cap, 1), dtype=torch.int32),
+                  "multi": torch.empty((max(d.n_rows, 1), 4), dtype=torch.int32)}
+        _native.check(lib.lgc_sweep_plan_export(handle, *(arrays[k].data_ptr() for k in
+                                                          ("slabs", "wave_slab_ptr", "wave_npieces", "piece_slot", "multi"))),
+                      "lgc_sweep_plan_export")
+    finally:
+        lib.lgc_sweep_plan_free(handle)
+    arrays["multi"] = arrays["multi"][:d.n_rows].contiguous()
+    arrays["multi"][:, 0] += row_begin                 # the planner saw rows 0 .. n of the slice
+    return dims, arrays
+
+
+class SweepPlan:
+    """Device arrays of a band-sweep plan (include/lgconv_hip.h, lgc_sweep_plan_*): built once per operator half on
+    the host from a host copy of its rows, uploaded, then applied with lgc_spmm_sweep."""
+
+    def __init__(self, rowptr: Tensor, entries: Tensor, row_begin: int, row_end: int, col_lo: int, col_hi: int,
+                 cfg: Optional[dict] = None):
+        dev = rowptr.device
+        self.dims, arrays = sweep_plan_host(rowptr, entries, row_begin, row_end, col_lo, col_hi, cfg)
+        self.row_begin, self.row_end = row_begin, row_end
+        self.slabs, self.wave_slab_ptr = arrays["slabs"].to(dev), arrays["wave_slab_ptr"].to(dev)
+        self.wave_npieces, self.piece_slot = arrays["wave_npieces"].to(dev), arrays["piece_slot"].to(dev)
+        # rows with up to WIDE_SLOTS partial slots are summed by one lane group each, the few with more by a wavefront
+        m = arrays["multi"]
+        wide = (m[:, 2] - m[:, 1]) > self.WIDE_SLOTS
+        self.multi, self.multi_wide = m[~wide].contiguous().to(dev), m[wide].contiguous().to(dev)
+        self._partials: Dict[int, Tensor] = {}
+
+    WIDE_SLOTS = 32
+
+    def partials(self, dim: int) -> Tensor:
+        buf = self._partials.get(dim)
+        if buf is None:
+            buf = torch.empty((max(self.dims["n_slots"], 1), dim), dtype=torch.float32, device=self.slabs.device)
+            self._partials[dim] = buf
+        return buf
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * 4 for t in (self.slabs, self.wave_slab_ptr, self.wave_npieces, self.piece_slot, self.multi,
+                                           self.multi_wide))
+
+
 @dataclass
 class Operator:
     """One sparse operator ready to be applied: CSR + plan (+ per-width scratch).
@@ -197,19 +274,40 @@ class Operator:
     entries: Tensor                      # int32 [E, 2]: column, fp32 bits of the value
     plan: RowPlan
     tiled: bool = False                  # rows up to plan.short_max go through the tiled kernels
+    sweep_cols: Optional[Tuple[int, int]] = None    # column range of a bipartite half that qualifies for the band sweep
+    _sweep: Optional[SweepPlan] = None
     _tiles: Optional[List[TileClass]] = None
     _partials: Dict[int, Tensor] = field(default_factory=dict)
 
     @classmethod
     def build(cls, n_rows: int, rowptr: Tensor, entries: Tensor, row_begin: int, row_end: int,
-              short_max: int = SHORT_MAX, chunk_len: int = CHUNK_LEN, tiles: Optional[bool] = None) -> "Operator":
+              short_max: int = SHORT_MAX, chunk_len: int = CHUNK_LEN, tiles: Optional[bool] = None,
+              sweep_cols: Optional[Tuple[int, int]] = None) -> "Operator":
         """Work plan for rows [row_begin, row_end) of a CSR.  With tiles, every row of at most
-        min(short_max, 32) entries is a tiled row and every longer one is chunked."""
+        min(short_max, 32) entries is a tiled row and every longer one is chunked.  ``sweep_cols`` = (lo, hi): every
+        column of these rows lies in [lo, hi) (a bipartite half) -- the rows may then run as a band sweep."""
         use_tiles = USE_TILES if tiles is None else tiles
         if use_tiles and rowptr.is_cuda:
             short_max = min(short_max, TILE_WIDTHS[-1])
-        return cls(n_rows, rowptr, entries, build_row_plan(rowptr, row_begin, row_end, short_max, chunk_len),
-                   bool(use_tiles and rowptr.is_cuda))
+        op = cls(n_rows, rowptr, entries, build_row_plan(rowptr, row_begin, row_end, short_max, chunk_len),
+                 bool(use_tiles and rowptr.is_cuda))
+        if sweep_cols is not None and rowptr.is_cuda and USE_SWEEP != "0" and sweep_cols[1] <= 0xFFFFFF:
+            # long rows over a table far beyond the caches: the item half of a user|item graph, not its user half
+            n_ent = int(rowptr[row_end]) - int(rowptr[row_begin])
+            n_cols = int(sweep_cols[1]) - int(sweep_cols[0])
+            long_rows = n_ent >= 8 * max(row_end - row_begin, 1)
+            if long_rows and (USE_SWEEP == "1" or (n_ent >= SWEEP_MIN_ENTRIES and n_cols >= 1 << 17)):
+                op.sweep_cols = (int(sweep_cols[0]), int(sweep_cols[1]))
+        return op
+
+    @property
+    def sweep(self) -> Optional[SweepPlan]:
+        if self.sweep_cols is None:
+            return None
+        if self._sweep is None:
+            p = self.plan
+            self._sweep = SweepPlan(self.rowptr, self.entries, p.row_begin, p.row_end, *self.sweep_cols)
+        return self._sweep
 
     @property
     def tiles(self) -> List[TileClass]:
@@ -259,6 +357,18 @@ class Operator:
         tiled = self.tiled and dim >= 4
         r_ptr, r_stride = _native.ptr(r), (0 if r is None else r.stride(0))
         stream = _native.stream_of(x.device)
+        if self.sweep_cols is not None and lib.lgc_sweep_ok(dim, table_rows, x.stride(0)):
+            sw = self.sweep
+            with torch.cuda.device(x.device):
+                code = lib.lgc_spmm_sweep(
+                    _native.ptr(sw.slabs), _native.ptr(sw.wave_slab_ptr), _native.ptr(sw.wave_npieces),
+                    _native.ptr(sw.piece_slot), sw.dims["n_waves"], sw.dims["row_cap"],
+                    _native.ptr(sw.multi) if sw.multi.size(0) else None, sw.multi.size(0),
+                    _native.ptr(sw.multi_wide) if sw.multi_wide.size(0) else None, sw.multi_wide.size(0),
+                    _native.ptr(sw.partials(dim)), table_rows, _native.ptr(x), x.stride(0),
+                    _native.ptr(out), out.stride(0), r_ptr, r_stride, float(a), float(b), dim, stream)
+            _native.check(code, "lgc_spmm_sweep")
+            return out
         with torch.cuda.device(x.device):
             # long rows first (they run longest); with tiles the row part of lgc_spmm gets an empty range
             if not tiled or p.n_chunks:
@@ -364,8 +474,11 @@ class PropGraph:
         got = self._halves.get(transpose)
         if got is None:
             op = self.transpose_op if transpose else self.forward_op
-            got = tuple(Operator.build(op.n_rows, op.rowptr, op.entries, lo, hi, self.short_max, self.chunk_len)
-                        for lo, hi in ((0, self.split), (self.split, self.num_nodes)))
+            # every column of a user row is an item and vice versa: each half may sweep the other side's range
+            got = tuple(Operator.build(op.n_rows, op.rowptr, op.entries, lo, hi, self.short_max, self.chunk_len,
+                                       sweep_cols=cols)
+                        for (lo, hi), cols in (((0, self.split), (self.split, self.num_nodes)),
+                                               ((self.split, self.num_nodes), (0, self.split))))
             self._halves[transpose] = got
         return got
 

@@ -162,6 +162,57 @@ int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries,
              const float *r, int64_t r_stride,
              float a, float b, int32_t dim, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Band sweep: long rows over a gathered table far larger than the caches (the item step of a user|item graph).
+ *
+ * Same hop as lgc_spmm's chunked rows (one LGConv layer, src/lightgcn.py:96, epilogue of :93,97), organised so that a
+ * row of the gathered table crosses the memory fabric about once per pass instead of once per use: the columns
+ * [col_lo, col_hi) are cut into n_bands ranges (one per XCD), every (row, band) pair gets an accumulator in LDS, and
+ * all wavefronts of a band walk its columns in ascending order together.  Sums are taken per piece in column order
+ * and per row in band order: deterministic, different association from lgc_spmm (inside the 1e-5 gate).
+ *
+ * The plan is built on the HOST from host copies of the CSR (the only entry points that take host pointers):
+ *   lgc_sweep_plan_create  rows [row_begin, row_end) of the CSR; returns NULL and sets *code on error
+ *   lgc_sweep_plan_dims    sizes of the arrays below
+ *   lgc_sweep_plan_export  copies them into caller-provided HOST buffers:
+ *       slabs uint32 [n_slabs * 256], wave_slab_ptr int32 [n_waves + 1], wave_npieces int32 [n_waves],
+ *       piece_slot int32 [n_waves * row_cap], multi lgc_multi_row [n_rows]
+ *   lgc_sweep_plan_free
+ * The caller uploads the arrays and passes device pointers to lgc_spmm_sweep, with a scratch `partials` of
+ * n_slots * dim floats.  The rows of `multi` may be split over two lists: `multi` (one lane group per row, for rows
+ * with few slots) and `multi_wide` (one wavefront per row, for rows cut into many pieces); every row in exactly one.  lgc_sweep_ok says whether a table qualifies (61..64 columns, < 2^24 - 1 rows, < 4 GiB).
+ */
+typedef struct lgc_sweep_cfg {
+    int32_t n_bands;               /* 8: one band per XCD (blockIdx % 8)                               */
+    int32_t waves_per_band_round;  /* 512: 32 CUs x 16 wavefronts                                      */
+    int32_t row_cap;               /* 39: accumulators per wavefront (16 x 40 rows x 256 B = 160 KiB)  */
+    int32_t piece_cap;             /* 64: longest run of one row's entries inside one wavefront's list; raised in
+                                      steps of 16 (up to 4x) while that saves a whole round                */
+    int32_t lookahead;             /* 64: how far the step builder looks for an entry of another piece  */
+} lgc_sweep_cfg;
+
+typedef struct lgc_sweep_dims {
+    int32_t n_bands, rounds, row_cap, piece_cap, n_rows, reserved;
+    int64_t n_waves, n_slabs, n_slots, n_entries, n_steps, n_padding;
+} lgc_sweep_dims;
+
+typedef struct lgc_sweep_plan lgc_sweep_plan;
+
+lgc_sweep_plan *lgc_sweep_plan_create(const int32_t *rowptr_host, const lgc_entry *entries_host, int32_t row_begin,
+                                      int32_t row_end, int32_t col_lo, int32_t col_hi, const lgc_sweep_cfg *cfg,
+                                      int *code);
+int lgc_sweep_plan_dims(const lgc_sweep_plan *plan, lgc_sweep_dims *dims);
+int lgc_sweep_plan_export(const lgc_sweep_plan *plan, uint32_t *slabs, int32_t *wave_slab_ptr, int32_t *wave_npieces,
+                          int32_t *piece_slot, lgc_multi_row *multi);
+void lgc_sweep_plan_free(lgc_sweep_plan *plan);
+
+int lgc_sweep_ok(int32_t dim, int64_t table_rows, int64_t x_stride);
+
+int lgc_spmm_sweep(const uint32_t *slabs, const int32_t *wave_slab_ptr, const int32_t *wave_npieces,
+                   const int32_t *piece_slot, int64_t n_waves, int32_t row_cap, const lgc_multi_row *multi,
+                   int32_t n_rows, const lgc_multi_row *multi_wide, int32_t n_wide, float *partials, int64_t table_rows, const float *x, int64_t x_stride, float *y,
+                   int64_t y_stride, const float *r, int64_t r_stride, float a, float b, int32_t dim, void *stream);
+
 /* y[i, :dim] = sum_t coef[t] * src[t][i, :dim]  for i < n_rows, terms added in index order, each product
  * rounded before its add -- the order of the reference's running layer sum `out = out + x * alpha`
  * (src/lightgcn.py:93,97).  `src`, `src_stride`, `coef` are HOST arrays of n_terms (1..LGC_MAX_TERMS) entries;

@@ -617,3 +617,52 @@ def test_tampered_saved_graph_is_refused_at_load(device, tmp_path):
     with pytest.raises(ValueError):
         PropGraph.load(str(tmp_path / "bad4.safetensors"), device)
     PropGraph.load(path, device)
+
+
+@pytest.mark.parametrize("dim", [64, 61])
+def test_band_sweep_matches_the_oracle_and_the_chunked_path(device, dim, monkeypatch):
+    """lgc_spmm_sweep (LDS accumulators per (row, band), column-sorted sums, fixed-order combine) on the item half of a
+    bipartite graph, forced on at a size where 'auto' would not pick it: vs the oracle hop (1e-5, norm-wise) and vs the
+    chunked path; deterministic; epilogue, scaling and a strided table included."""
+    from gnn_ecommerce_amd import graph as G
+    from gnn_ecommerce_amd.graph import Operator
+    g, ei, ew = small_graph(8, 6000, 150, 90000)
+    n, nu = g.num_nodes, g.n_users
+    pg = PropGraph(ei.to(device), ew.to(device), n)
+    op = pg.forward_op
+    x, r = synth.xavier_table(n, dim, 5), synth.xavier_table(n, dim, 6)
+    want = oracle.lgconv(x, ei, ew)
+    xd, rd = x.to(device), r.to(device)
+    monkeypatch.setattr(G, "USE_SWEEP", "1")
+    for cfg in (dict(waves_per_band_round=8, row_cap=20, piece_cap=16), dict(waves_per_band_round=4, row_cap=78)):
+        monkeypatch.setattr(G, "SWEEP_CFG", dict(G.SWEEP_CFG, **cfg))
+        sw = Operator.build(n, op.rowptr, op.entries, nu, n, 32, 256, sweep_cols=(0, nu))
+        assert sw.sweep_cols == (0, nu)
+        y = torch.full((n, dim), float("nan"), device=device)
+        sw.apply(xd, y)
+        assert sw._sweep is not None and sw._sweep.dims["n_entries"] == g.nnz // 2
+        got = y[nu:].cpu()
+        assert rel_fro(got, want[nu:]) <= TOL and worst_row_rel(got, want[nu:]) <= TOL
+        assert torch.isnan(y[:nu]).all()                                   # only the rows of the plan are written
+        y2 = torch.empty_like(y)
+        sw.apply(xd, y2)
+        assert torch.equal(y2[nu:], y[nu:])                                # deterministic
+        ye = torch.empty_like(y)
+        sw.apply(xd, ye, a=0.5, r=rd, b=0.25)
+        want_e = 0.5 * want[nu:] + 0.25 * r[nu:]
+        assert rel_fro(ye[nu:].cpu(), want_e) <= TOL
+        wide = torch.zeros((n, dim + 8), device=device)
+        wide[:, :dim] = xd
+        ys = torch.empty_like(y)
+        sw.apply(wide[:, :dim], ys)
+        assert torch.equal(ys[nu:], y[nu:])
+    chunked = Operator.build(n, op.rowptr, op.entries, nu, n, 32, 256)
+    assert chunked.sweep_cols is None
+    yc = torch.empty((n, dim), device=device)
+    chunked.apply(xd, yc)
+    assert rel_fro(y[nu:].cpu(), yc[nu:].cpu()) <= 1e-6
+    # a width the sweep does not take falls back to the chunked path of the same operator
+    x90 = synth.xavier_table(n, 90, 5, device)
+    y90 = torch.empty_like(x90)
+    sw.apply(x90, y90)
+    assert rel_fro(y90[nu:].cpu(), oracle.lgconv(x90.cpu(), ei, ew)[nu:]) <= TOL
