@@ -61,6 +61,7 @@ SIGNATURES = {
                                c_int32, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float, c_float,
                                c_int32, c_void_p]),
     "lgc_lincomb": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p]),
+    "lgc_mask_topk": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "lgc_sample_triples": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_uint64,
                                    c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lgc_pair_dot": (c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_int64, c_void_p,

@@ -995,6 +995,129 @@ __global__ __launch_bounds__(kBlock) void k_pair_dot_bwd(const float *__restrict
 }
 
 // ----------------------------------------------------------------------------------------
+// Serving tail: multiplicative seen-mask + top-k per row, on the device
+// ----------------------------------------------------------------------------------------
+// masked[i] = score[i] * (1 - seen[i])  (src/lightgcn.py:175 -- seen items become 0, they are not removed), then the
+// k largest by (value descending, index ascending).  One workgroup per row: three radix passes (11 + 11 + 10 bits of
+// an order-preserving key, histograms in LDS) find the k-th largest key T, one pass collects everything above T plus
+// as many elements equal to T as are still needed -- lowest indices first -- and a bitonic sort orders the k winners.
+// The row is re-read from L2 (218 KB at 54,571 items), nothing but [rows, k] indices leaves the device.
+constexpr int kTopkMax = 256;
+constexpr int kTopkBlock = 1024;   // 16 wavefronts on one row: a single-row request is latency-bound on one CU
+
+__device__ __forceinline__ uint32_t order_key(float v) {
+    const uint32_t u = __float_as_uint(__fadd_rn(v, 0.0f));   // -0 -> +0: they compare equal (a seen item's 0 * score)
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);        // ascending with the value; +NaN above +inf like torch.topk
+}
+
+__global__ __launch_bounds__(kTopkBlock) void k_mask_topk(const float *__restrict__ scores, int64_t score_stride,
+                                                         const float *__restrict__ seen, int64_t seen_stride, int32_t n_cols,
+                                                         int32_t k, int64_t *__restrict__ out_index,
+                                                         float *__restrict__ out_value) {
+    __shared__ uint32_t hist[2048];
+    __shared__ unsigned long long cand[kTopkMax];
+    __shared__ uint32_t sh_bin, sh_need, sh_count, sh_wave[kTopkBlock / kWave];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+    const float *srow = scores + (int64_t)blockIdx.x * score_stride;
+    const float *mrow = seen ? seen + (int64_t)blockIdx.x * seen_stride : nullptr;
+    auto masked = [&](float s, float m) { return mrow ? __fmul_rn(s, __fsub_rn(1.0f, m)) : s; };
+    uint32_t prefix = 0, mask = 0, need = (uint32_t)k, eq_total = 0;
+    const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+    for (int pass = 0; pass < 3; ++pass) {
+        const int shift = shifts[pass], nb = 1 << bits[pass];
+        for (int b = tid; b < 2048; b += kTopkBlock) hist[b] = 0;
+        __syncthreads();
+        for (int base = 0; base < n_cols; base += 4 * kTopkBlock) {   // four independent loads per thread in flight
+            float sv[4], mv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = base + j * kTopkBlock + tid;
+                sv[j] = i < n_cols ? srow[i] : 0.0f;
+                mv[j] = (mrow && i < n_cols) ? mrow[i] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = base + j * kTopkBlock + tid;
+                const uint32_t key = order_key(masked(sv[j], mv[j]));
+                if (i < n_cols && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & (nb - 1)], 1u);
+            }
+        }
+        __syncthreads();
+        if (wv == 0) {   // lane L owns `per` bins counted from the top: walk down until `need` elements are covered
+            const int per = nb / kWave;
+            uint32_t mine = 0;
+            for (int j = 0; j < per; ++j) mine += hist[nb - 1 - (lane * per + j)];
+            uint32_t incl = mine;   // inclusive scan over lanes (lane 0 = highest bins)
+            for (int off = 1; off < kWave; off <<= 1) {
+                const uint32_t o = __shfl_up(incl, off);
+                if (lane >= off) incl += o;
+            }
+            const uint32_t before = incl - mine;
+            if (before < need && incl >= need) {     // exactly one lane
+                uint32_t acc = before;
+                for (int j = 0; j < per; ++j) {
+                    const int b = nb - 1 - (lane * per + j);
+                    if (acc + hist[b] >= need) { sh_bin = (uint32_t)b; sh_need = need - acc; sh_count = hist[b]; break; }
+                    acc += hist[b];
+                }
+            }
+        }
+        __syncthreads();
+        prefix |= sh_bin << shift;
+        mask |= (uint32_t)(nb - 1) << shift;
+        need = sh_need;
+        eq_total = sh_count;
+        __syncthreads();
+    }
+    const uint32_t T = prefix, n_gt = (uint32_t)k - need;   // take all keys > T (n_gt of them) and `need` keys == T
+    if (tid == 0) sh_count = 0;
+    for (int i = tid; i < kTopkMax; i += kTopkBlock) cand[i] = 0ull;
+    __syncthreads();
+    const bool ties_cut = eq_total > need;                  // more elements equal T than fit: lowest indices win
+    uint32_t eq_taken = 0;                                  // block-uniform, only used when ties_cut
+    for (int base = 0; base < n_cols; base += kTopkBlock) {
+        const int i = base + tid;
+        const uint32_t key = i < n_cols ? order_key(masked(srow[i], mrow ? mrow[i] : 0.0f)) : 0u;
+        const bool gt = i < n_cols && key > T, eq = i < n_cols && key == T;
+        if (gt || (eq && !ties_cut)) {
+            const uint32_t pos = atomicAdd(&sh_count, 1u);
+            cand[pos] = ((unsigned long long)key << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i);
+        }
+        if (ties_cut && eq_taken < need) {   // ordered by index: ballots + per-wave offsets (rare: exact ties at the cut)
+            const unsigned long long bal = __ballot(eq);
+            if (lane == 0) sh_wave[wv] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            uint32_t off = eq_taken, tot = 0;
+            for (int q = 0; q < kTopkBlock / kWave; ++q) { if (q < wv) off += sh_wave[q]; tot += sh_wave[q]; }
+            const uint32_t rank = off + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            if (eq && rank < need)
+                cand[n_gt + rank] = ((unsigned long long)key << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i);
+            eq_taken += tot;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    // bitonic sort, descending, of the kTopkMax candidate slots (unused slots are 0 = below every real key)
+    for (int size = 2; size <= kTopkMax; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const int a = tid, b = tid ^ stride;
+            if (a < kTopkMax && b > a) {
+                const bool desc = (a & size) == 0;
+                const unsigned long long x = cand[a], y = cand[b];
+                if (desc ? x < y : x > y) { cand[a] = y; cand[b] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid < k) {
+        const unsigned long long c = cand[tid];
+        const uint32_t idx = 0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFull);
+        out_index[(int64_t)blockIdx.x * k + tid] = (int64_t)idx;
+        if (out_value) out_value[(int64_t)blockIdx.x * k + tid] = masked(srow[idx], mrow ? mrow[idx] : 0.0f);
+    }
+}
+
+// ----------------------------------------------------------------------------------------
 // Mini-batch sampler
 // ----------------------------------------------------------------------------------------
 // splitmix64 finaliser as a counter-based generator: draw(seed, step, sample, attempt) is stateless.
@@ -1606,6 +1729,18 @@ int lgc_pair_dot_backward(const float *grad_scores, const float *emb, int64_t st
     if (!idx0 || !idx1 || !grad_scores) return LGC_E_INVAL;
     hipLaunchKernelGGL(k_pair_dot_bwd, dim3(ceil_div(n_pairs, kBlock / kWave)), dim3(kBlock), 0, as_stream(stream_),
                        grad_scores, emb, stride, dim, n_nodes, idx0, idx1, n_pairs, grad_emb, status);
+    return (int)hipGetLastError();
+}
+
+int lgc_mask_topk(const float *scores, int64_t score_stride, const float *seen, int64_t seen_stride, int64_t n_rows,
+                  int32_t n_cols, int32_t k, int64_t *out_index, float *out_value, void *stream_) {
+    if (!scores || !out_index || n_rows < 0 || n_cols < 1 || k < 1 || k > n_cols || score_stride < n_cols ||
+        (seen && seen_stride < n_cols) || n_rows >= INT32_MAX)
+        return LGC_E_INVAL;
+    if (k > kTopkMax) return LGC_E_RANGE;
+    if (n_rows == 0) return 0;
+    hipLaunchKernelGGL(k_mask_topk, dim3((unsigned)n_rows), dim3(kTopkBlock), 0, as_stream(stream_), scores, score_stride, seen,
+                       seen_stride, n_cols, k, out_index, out_value);
     return (int)hipGetLastError();
 }
 

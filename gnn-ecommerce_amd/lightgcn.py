@@ -21,7 +21,7 @@ from torch.nn.modules.loss import _Loss
 from . import _native
 from .graph import get_graph
 from .lgconv import LGConv
-from .propagate import pair_dot, propagate_sum
+from .propagate import TOPK_MAX, mask_topk, pair_dot, propagate_sum
 
 __all__ = ["LightGCN", "BPRLoss", "LGConv"]
 
@@ -134,9 +134,21 @@ class LightGCN(torch.nn.Module):
         import pandas as pd
         embeds = self._serving_embedding(edge_index, edge_weight)
         users, items = torch.split(embeds, [n_users, n_items])
-        pred = (users[user_id_list] @ items.t()).cpu()
-        top_index = torch.mul(pred, (1 - interactions_t)).topk(k, dim=-1).indices
-        frame = pd.DataFrame(top_index.numpy())
+        # Scores, the multiplicative seen-mask and the top-k all stay on the device: only the [n_sel, k] indices
+        # come back (upstream ships the whole [n_sel, n_items] score matrix to the host first, :174).  Same fp32
+        # products as ``torch.mul(pred.cpu(), 1 - interactions_t)``; the mask may already live on the device.
+        sel = torch.as_tensor(user_id_list, device=embeds.device) if not torch.is_tensor(user_id_list) \
+            else user_id_list.to(embeds.device)
+        pred = users.index_select(0, sel.reshape(-1).long()) @ items.t()
+        seen = interactions_t.to(device=embeds.device, dtype=pred.dtype, non_blocking=True)
+        if k <= TOPK_MAX:
+            top_index = mask_topk(pred, seen.expand_as(pred).contiguous(), k).cpu()       # one launch: lgc_mask_topk
+        else:
+            top_index = torch.mul(pred, (1 - seen)).topk(k, dim=-1).indices.cpu()
+        if isinstance(user_id_list, (list, tuple)):
+            # the frame upstream builds in three steps (:178-182), built directly: same columns, dtypes, index, values
+            return pd.DataFrame({'user_ID': list(user_id_list), 'top_rlvnt_itm': top_index.numpy().tolist()})
+        frame = pd.DataFrame(top_index.numpy())           # anything index-carrying (a Series): upstream's own steps
         frame['top_rlvnt_itm'] = frame.values.tolist()
         frame['user_ID'] = user_id_list
         return frame[['user_ID', 'top_rlvnt_itm']]

@@ -237,3 +237,31 @@ def pair_dot(emb: Tensor, edge_label_index: Tensor) -> Tensor:
     if emb.dtype != torch.float32 or emb.dim() != 2:
         raise TypeError("embeddings must be a 2-D fp32 tensor")
     return _PairDot.apply(emb, edge_label_index[0], edge_label_index[1])
+
+
+# ----------------------------------------------------------------------------------------
+# serving tail: seen-mask + top-k on the device
+# ----------------------------------------------------------------------------------------
+TOPK_MAX = 256
+
+
+def mask_topk(scores: Tensor, seen: Optional[Tensor], k: int) -> Tensor:
+    """Indices [rows, k] (int64, on the device) of the k largest ``scores * (1 - seen)`` per row, ties by lower index
+    (src/lightgcn.py:175-177).  ``seen`` may be None.  k <= 256."""
+    _native.require_device(scores, "scores")
+    if scores.dtype != torch.float32 or scores.dim() != 2 or scores.stride(1) != 1:
+        raise TypeError("scores must be a 2-D fp32 tensor with unit inner stride")
+    if seen is not None:
+        _native.require_device(seen, "seen mask")
+        if seen.dtype != torch.float32 or seen.shape != scores.shape or seen.stride(1) != 1:
+            raise TypeError("the seen mask must be fp32 of the scores' shape")
+    rows, cols = scores.shape
+    if not 1 <= k <= cols:
+        raise RuntimeError(f"selected index k out of range: k={k}, {cols} columns")      # torch.topk's error class
+    out = torch.empty((rows, k), dtype=torch.int64, device=scores.device)
+    lib = _native.load()
+    with torch.cuda.device(scores.device):
+        code = lib.lgc_mask_topk(_native.ptr(scores), scores.stride(0), _native.ptr(seen), 0 if seen is None else seen.stride(0),
+                                 rows, cols, k, _native.ptr(out), None, _native.stream_of(scores.device))
+    _native.check(code, "lgc_mask_topk")
+    return out

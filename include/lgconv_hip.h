@@ -238,6 +238,15 @@ int lgc_pair_dot_backward(const float *grad_scores, const float *emb, int64_t st
                           const int64_t *idx0, const int64_t *idx1, int64_t n_pairs,
                           float *grad_emb, int32_t *status, void *stream);
 
+/* Serving tail of LightGCN.recommendK (src/lightgcn.py:175-177; called per request from
+ * torchserve/lightgcn_handler.py:91): masked = scores * (1 - seen), then per row the k largest by
+ * (value descending, index ascending), entirely on the device -- upstream copies the [rows, n_cols] score matrix
+ * to the host first.  seen may be NULL (no mask).  k <= 256 (LGC_E_RANGE beyond).
+ *   scores fp32 [n_rows, n_cols] (row stride in floats), seen fp32 same shape,
+ *   out_index int64 [n_rows, k], out_value fp32 [n_rows, k] or NULL. */
+int lgc_mask_topk(const float *scores, int64_t score_stride, const float *seen, int64_t seen_stride, int64_t n_rows,
+                  int32_t n_cols, int32_t k, int64_t *out_index, float *out_value, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Mini-batch sampler: for each of the `n` given users one positive and one negative item.
  * Replaces the per-row Python of batch_loader (src/utils_v2.py:168-181; its caller

@@ -666,3 +666,59 @@ def test_band_sweep_matches_the_oracle_and_the_chunked_path(device, dim, monkeyp
     y90 = torch.empty_like(x90)
     sw.apply(x90, y90)
     assert rel_fro(y90[nu:].cpu(), oracle.lgconv(x90.cpu(), ei, ew)[nu:]) <= TOL
+
+
+@pytest.mark.parametrize("rows,cols,k", [(1, 54571, 20), (7, 1000, 5), (3, 300, 256), (5, 64, 64), (2, 5000, 1)])
+def test_mask_topk_matches_torch_and_breaks_ties_by_index(device, rows, cols, k):
+    from gnn_ecommerce_amd.propagate import mask_topk
+    gen = torch.Generator().manual_seed(rows * 1000 + k)
+    scores = torch.randn(rows, cols, generator=gen)
+    seen = (torch.rand(rows, cols, generator=gen) < 0.1).float()
+    masked = scores * (1 - seen)
+    want = masked.topk(k, dim=-1)
+    got = mask_topk(scores.to(device), seen.to(device), k).cpu()
+    assert got.dtype == torch.int64 and got.shape == (rows, k)
+    assert torch.equal(torch.gather(masked, 1, got), want.values)                 # the same values in the same order
+    assert all(len(set(r)) == k for r in got.tolist())
+    # no mask; a strided view of the scores
+    wide = torch.randn(rows, cols + 5, generator=gen).to(device)
+    got2 = mask_topk(wide[:, :cols], None, k).cpu()
+    assert torch.equal(torch.gather(wide[:, :cols].cpu(), 1, got2), wide[:, :cols].cpu().topk(k, dim=-1).values)
+    # exact ties at the cut: equal values are taken lowest index first, and sorted by (value desc, index asc)
+    tied = torch.zeros(rows, cols)
+    tied[:, 3::7] = 2.0
+    tied[:, 5] = 9.0
+    idx = mask_topk(tied.to(device), None, min(k, cols)).cpu()
+    order = sorted(range(cols), key=lambda i: (-tied[0, i].item(), i))[:min(k, cols)]
+    assert idx[0].tolist() == order
+    # everything seen: all zeros -> indices 0 .. k-1
+    assert mask_topk(scores.to(device), torch.ones(rows, cols, device=device), k).cpu()[0].tolist() == list(range(k))
+    with pytest.raises(RuntimeError):
+        mask_topk(scores.to(device), None, cols + 1)
+
+
+def test_recommendk_frame_is_upstreams_frame(device):
+    """Columns, dtypes, index and values of the fast frame construction vs upstream's three steps; a Series of user ids
+    (index-aligned assignment upstream) takes upstream's own steps."""
+    import pandas as pd
+    g, ei, ew = small_graph(2, 200, 50, 1500)
+    model = lg.LightGCN(g.num_nodes, 64, 2).to(device).eval()
+    users = [3, 9, 27, 120]
+    seen = torch.zeros(len(users), g.n_items)
+    seen[1, :10] = 1.0
+    with torch.no_grad():
+        frame = model.recommendK(ei.to(device), ew.to(device), g.n_users, g.n_items, seen, users, 7)
+        emb = model.get_embedding(ei.to(device), ew.to(device)).cpu()
+        frame_dev = model.recommendK(ei.to(device), ew.to(device), g.n_users, g.n_items, seen.to(device), users, 7)
+        frame_ser = model.recommendK(ei.to(device), ew.to(device), g.n_users, g.n_items, seen, pd.Series(users), 7)
+    top = oracle.recommend_topk(emb, g.n_users, g.n_items, seen, users, 7)
+    ref = pd.DataFrame(top.numpy())
+    ref['top_rlvnt_itm'] = ref.values.tolist()
+    ref['user_ID'] = users
+    ref = ref[['user_ID', 'top_rlvnt_itm']]
+    assert list(frame.columns) == list(ref.columns) and frame.dtypes.tolist() == ref.dtypes.tolist()
+    assert frame.index.equals(ref.index) and frame['user_ID'].tolist() == users
+    assert frame.equals(frame_dev) and frame['top_rlvnt_itm'].tolist() == frame_ser['top_rlvnt_itm'].tolist()
+    users_e, items_e = torch.split(emb, [g.n_users, g.n_items])
+    assert_topk_exact_up_to_ties(np.array(frame['top_rlvnt_itm'].tolist()), top.numpy(),
+                                 ((users_e[users] @ items_e.t()) * (1 - seen)).numpy())

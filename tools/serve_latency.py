@@ -16,6 +16,15 @@ out = {}
 for n_users in (1, 64):
     users = list(range(7, 7 + n_users))
     seen = torch.zeros(n_users, g.n_items)
+    seen_dev = seen.to(dev)                      # a caller that keeps its interaction rows on the device
+    model.cache_recommend_embeddings = True
+    ts = []
+    with torch.no_grad():
+        for _ in range(23):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            model.recommendK(ei, ew, g.n_users, g.n_items, seen_dev, users, 20)
+            ts.append((time.perf_counter() - t0) * 1e3)
+    out[f"users{n_users}_reuse_devmask_ms"] = round(statistics.median(ts[3:]), 3)
     for reuse in (True, False):
         model.cache_recommend_embeddings = reuse
         ts = []
