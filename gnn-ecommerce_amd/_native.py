@@ -60,6 +60,8 @@ SIGNATURES = {
     "lgc_spmm_sweep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int32, c_void_p,
                                c_int32, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float, c_float,
                                c_int32, c_void_p]),
+    "lgc_seed_push": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p, c_int64, c_int32,
+                              c_void_p]),
     "lgc_lincomb": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p]),
     "lgc_mask_topk": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "lgc_sample_triples": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_uint64,

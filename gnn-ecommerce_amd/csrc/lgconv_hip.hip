@@ -925,6 +925,34 @@ __global__ __launch_bounds__(kBlock) void k_sweep_combine(SpmmArgs p, const lgc_
     finish_row<VEC, SpmmArgs>(p, mr.row, c0, acc, rv);
 }
 
+// Seeded transpose step: y[col] += val * g[s] for every entry (col, val) of row seed_rows[s] -- the first backward hop
+// of a training step, whose incoming gradient has at most 2B non-zero user rows (src/lightgcn.py:123-125 scores 2B
+// pairs): the dense item step would gather 10 M rows of zeros.  One wavefront per seed row, lane groups stride its
+// entries, fp32 atomics into the (pre-zeroed) output rows: a few thousand edges in all.
+__global__ __launch_bounds__(kBlock) void k_seed_push(const int32_t *__restrict__ rowptr, const lgc_entry *__restrict__ entries,
+                                                     const int64_t *__restrict__ seed_rows, const float *__restrict__ seed_vals,
+                                                     int64_t n_seed, int64_t n_rows, float scale, float *__restrict__ y,
+                                                     int64_t y_stride, int32_t dim) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t s = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x / kWave);
+    if (s >= n_seed) return;
+    const int64_t row = seed_rows[s];
+    if (row < 0 || row >= n_rows) return;
+    const int lpr = (dim + 3) / 4, groups = kWave / lpr;
+    const int g = lane / lpr, l = lane - g * lpr;
+    if (g >= groups) return;
+    const int c0 = l * 4;
+    float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = 0; i < 4; ++i)
+        if (c0 + i < dim) v[i] = __fmul_rn(scale, seed_vals[s * dim + c0 + i]);
+    for (int32_t k = rowptr[row] + g; k < rowptr[row + 1]; k += groups) {
+        const lgc_entry e = entries[k];
+        float *dst = y + (int64_t)e.col * y_stride + c0;
+        for (int i = 0; i < 4; ++i)
+            if (c0 + i < dim) atomicAdd(dst + i, __fmul_rn(e.val, v[i]));
+    }
+}
+
 struct LincombArgs {
     const float *src[LGC_MAX_TERMS];
     int64_t stride[LGC_MAX_TERMS];
@@ -1689,6 +1717,16 @@ int lgc_spmm_sweep(const uint32_t *slabs, const int32_t *wave_slab_ptr, const in
         hipLaunchKernelGGL((k_sweep_combine<4>), dim3(n_wide + ceil_div(n_rows, rows_per_block)), dim3(kBlock), 0, stream, sp,
                            multi_wide, n_wide, multi, n_rows, partials);
     }
+    return (int)hipGetLastError();
+}
+
+int lgc_seed_push(const int32_t *rowptr, const lgc_entry *entries, const int64_t *seed_rows, const float *seed_vals,
+                  int64_t n_seed, int64_t n_rows, float scale, float *y, int64_t y_stride, int32_t dim, void *stream_) {
+    if (!rowptr || !y || n_seed < 0 || n_rows < 0 || dim < 1 || dim > 256 || y_stride < dim) return LGC_E_INVAL;
+    if (n_seed == 0) return 0;
+    if (!seed_rows || !seed_vals || !entries) return LGC_E_INVAL;
+    hipLaunchKernelGGL(k_seed_push, dim3(ceil_div(n_seed, kBlock / kWave)), dim3(kBlock), 0, as_stream(stream_), rowptr, entries,
+                       seed_rows, seed_vals, n_seed, n_rows, scale, y, y_stride, dim);
     return (int)hipGetLastError();
 }
 

@@ -21,7 +21,7 @@ from torch.nn.modules.loss import _Loss
 from . import _native
 from .graph import get_graph
 from .lgconv import LGConv
-from .propagate import TOPK_MAX, mask_topk, pair_dot, propagate_sum
+from .propagate import TOPK_MAX, mask_topk, pair_dot, propagate_sum, scores_from_table
 
 __all__ = ["LightGCN", "BPRLoss", "LGConv"]
 
@@ -106,8 +106,11 @@ class LightGCN(torch.nn.Module):
                 edge_label_index = torch.stack(edge_index.coo()[:2], dim=0)
             else:
                 edge_label_index = edge_index
-        out = self.get_embedding(edge_index, edge_weight)
-        return pair_dot(out, edge_label_index)
+        x0 = self.embedding.weight
+        _native.require_device(x0, "LightGCN.embedding.weight")
+        normalize = self.convs[0].normalize if self.num_layers > 0 else True
+        graph = get_graph(edge_index, edge_weight, self.num_nodes, normalize)
+        return scores_from_table(x0, graph, self._alphas(), edge_label_index)
 
     # -- heads built on it -----------------------------------------------------------------
     def predict_link(self, edge_index, edge_label_index: Optional[Tensor] = None, prob: bool = False) -> Tensor:

@@ -228,6 +228,124 @@ class _PairDot(torch.autograd.Function):
         return grad, None, None
 
 
+# ----------------------------------------------------------------------------------------
+# scores straight from the weight table: forward = propagate + pair scoring, backward seeded
+# ----------------------------------------------------------------------------------------
+SPARSE_BACKWARD = os.environ.get("LGCN_SPARSE_BACKWARD", "1") == "1"
+# the seeded backward is used when the table has at least this many rows per possible seed row (2 per label pair)
+SEED_ROWS_FACTOR = int(os.environ.get("LGCN_SEED_ROWS_FACTOR", "32"))
+
+
+def _seed_push(op: Operator, rows: Tensor, vals: Tensor, scale: float, out: Tensor) -> None:
+    lib = _native.load()
+    with torch.cuda.device(out.device):
+        code = lib.lgc_seed_push(_native.ptr(op.rowptr), _native.ptr(op.entries), _native.ptr(rows), _native.ptr(vals),
+                                 rows.numel(), op.n_rows, float(scale), _native.ptr(out), out.stride(0), out.size(1),
+                                 _native.stream_of(out.device))
+    _native.check(code, "lgc_seed_push")
+
+
+def seeded_transpose_sum(graph: PropGraph, rows: Tensor, vals: Tensor, alphas: Sequence[float], n: int) -> Tensor:
+    """sum_l alpha_l (A^T)^l g for a gradient g given by its non-zero rows (``rows`` int64, repeats add up; ``vals`` [len, D])
+    on a user|item graph -- what ``_PropagateSum.backward`` computes from a dense g, without ever forming it:
+      * hop 1, item side: only edges that leave a seed USER matter -> lgc_seed_push over those users' rows of A
+        (A^T[i, u] = A[u, i]) instead of a dense item step gathering 10 M rows of zeros;
+      * hop 1, user side: the dense user step, reading only the 14 MB item block of g (the rest of that table is never
+        initialised, let alone zero-filled);
+      * the alpha_0 g term of the user rows is added to the <= 2B seed rows afterwards instead of being read as a dense
+        epilogue table by the last user step."""
+    k = len(alphas) - 1
+    split = graph.split
+    dim = vals.size(1)
+    dev = vals.device
+    # no compaction (that would be a host sync): a seed of the other side keeps its slot with row -1 / zero values
+    is_user = (rows < split).unsqueeze(1)
+    urows = torch.where(is_user.squeeze(1), rows, torch.full_like(rows, -1))          # lgc_seed_push skips row < 0
+    uvals = torch.where(is_user, vals, torch.zeros_like(vals))
+    irows = torch.where(is_user.squeeze(1), torch.zeros_like(rows), rows - split)
+    ivals = vals - uvals
+    g_tab = torch.empty((n, dim), dtype=torch.float32, device=dev)         # only the item block is ever read
+    g_items = g_tab[split:]
+    g_items.zero_()
+    g_items.index_add_(0, irows, ivals)
+    if k == 0:
+        out = torch.zeros((n, dim), dtype=torch.float32, device=dev)
+        out.index_add_(0, rows, vals, alpha=alphas[0])
+        return out
+    user_t, item_t = graph.halves(True)
+    user_fwd, _ = graph.halves(False)
+    tables = [g_tab]
+    out = None
+    for layer in range(1, k + 1):
+        with _HopSpan():
+            nxt = scratch_table(g_tab)
+            if layer == 1:
+                nxt[split:].zero_()
+                _seed_push(user_fwd, urows, uvals, 1.0, nxt)                    # x_1[items] from the seed users
+            else:
+                item_t.apply(tables[-1], nxt)
+            if layer < k:
+                user_t.apply(tables[-1], nxt)
+                tables.append(nxt)
+            else:
+                tables.append(nxt)
+                out = torch.empty((n, dim), dtype=torch.float32, device=dev)
+                mix = scratch_table(g_tab)
+                _native.lincomb(mix[split:], [(alphas[l], tables[l - 1][split:]) for l in range(1, k + 1)])
+                _native.lincomb(out[split:], [(alphas[l], tables[l][split:]) for l in range(0, k + 1)])
+                user_t.apply(mix, out, a=1.0)
+                out.index_add_(0, urows.clamp(min=0), uvals, alpha=alphas[0])   # + alpha_0 g on the seed users
+    return out
+
+
+class _ScoresFromTable(torch.autograd.Function):
+    """scores[m] = <out[i0_m], out[i1_m]> with out = sum_l alpha_l A^l w (src/lightgcn.py:121-125) as ONE autograd node:
+    keeps the 2M gathered rows instead of the [N, D] table, and runs the backward pass from the sparse seed."""
+
+    @staticmethod
+    def forward(ctx, w: Tensor, graph: PropGraph, alphas: tuple, idx0: Tensor, idx1: Tensor) -> Tensor:
+        lib = _native.load()
+        emb = _layer_sum(graph, w.detach(), alphas, transpose=False)
+        idx0, idx1 = idx0.contiguous(), idx1.contiguous()
+        scores = torch.empty(idx0.numel(), dtype=torch.float32, device=emb.device)
+        with torch.cuda.device(emb.device):
+            code = lib.lgc_pair_dot(_native.ptr(emb), emb.stride(0), emb.size(1), emb.size(0), _native.ptr(idx0),
+                                    _native.ptr(idx1), idx0.numel(), _native.ptr(scores), _native.ptr(_status(emb.device)),
+                                    _native.stream_of(emb.device))
+        _native.check(code, "lgc_pair_dot")
+        n = emb.size(0)
+        ok = (idx0 >= 0) & (idx0 < n) & (idx1 >= 0) & (idx1 < n)       # invalid pairs score NaN and carry no gradient
+        i0, i1 = idx0.clamp(0, n - 1), idx1.clamp(0, n - 1)
+        ctx.save_for_backward(emb[i0], emb[i1], i0, i1, ok)
+        ctx.graph, ctx.alphas, ctx.n = graph, alphas, n
+        return scores
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_scores: Tensor):
+        e0, e1, i0, i1, ok = ctx.saved_tensors
+        gs = torch.where(ok, grad_scores, torch.zeros_like(grad_scores)).unsqueeze(1)
+        rows = torch.cat([i0, i1])                                       # pairs that share a node simply add up
+        vals = torch.cat([gs * e1, gs * e0])                             # d score / d out[i0] = e1, d / d out[i1] = e0
+        return seeded_transpose_sum(ctx.graph, rows, vals, ctx.alphas, ctx.n), None, None, None, None
+
+
+def scores_from_table(w: Tensor, graph: PropGraph, alphas: Sequence[float], edge_label_index: Tensor) -> Tensor:
+    """``pair_dot(propagate_sum(w, graph, alphas), edge_label_index)``; with gradients on, a user|item graph and few
+    label pairs it runs as one node whose backward pass starts from the sparse seed."""
+    _native.require_device(w, "embedding table")
+    _native.require_device(edge_label_index, "edge_label_index")
+    if edge_label_index.dtype != torch.int64 or edge_label_index.dim() != 2 or edge_label_index.size(0) != 2:
+        raise TypeError("edge_label_index must be an int64 tensor of shape [2, M]")
+    alphas = tuple(float(a) for a in alphas)
+    sparse_ok = (SPARSE_BACKWARD and torch.is_grad_enabled() and w.requires_grad and graph.split is not None
+                 and USE_BIPARTITE and len(alphas) - 1 <= _native.MAX_TERMS - 1
+                 and 2 * edge_label_index.size(1) * SEED_ROWS_FACTOR <= w.size(0))   # a seed far smaller than the table
+    if not sparse_ok:
+        return pair_dot(propagate_sum(w, graph, alphas), edge_label_index)
+    return _ScoresFromTable.apply(w, graph, alphas, edge_label_index[0], edge_label_index[1])
+
+
 def pair_dot(emb: Tensor, edge_label_index: Tensor) -> Tensor:
     """scores[m] = <emb[idx[0, m]], emb[idx[1, m]]>  (src/lightgcn.py:123-125)."""
     _native.require_device(emb, "embeddings")

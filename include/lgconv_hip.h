@@ -213,6 +213,15 @@ int lgc_spmm_sweep(const uint32_t *slabs, const int32_t *wave_slab_ptr, const in
                    int32_t n_rows, const lgc_multi_row *multi_wide, int32_t n_wide, float *partials, int64_t table_rows, const float *x, int64_t x_stride, float *y,
                    int64_t y_stride, const float *r, int64_t r_stride, float a, float b, int32_t dim, void *stream);
 
+/* Seeded transpose step (first hop of the backward pass, loss.backward() at src/train_lightgcn.py:146): the incoming
+ * gradient of the scores of src/lightgcn.py:123-125 has non-zero rows only where a label pair points, so
+ *   y[col] += entries[k].val * scale * seed_vals[s]   for every entry k of row seed_rows[s]
+ * replaces the dense hop over the whole graph for those rows' side.  y must hold zeros (or the sum to add to);
+ * fp32 atomics: the order of the few thousand adds is not fixed.  seed_rows int64 [n_seed] (rows outside
+ * [0, n_rows) are skipped), seed_vals fp32 [n_seed, dim] dense. */
+int lgc_seed_push(const int32_t *rowptr, const lgc_entry *entries, const int64_t *seed_rows, const float *seed_vals,
+                  int64_t n_seed, int64_t n_rows, float scale, float *y, int64_t y_stride, int32_t dim, void *stream);
+
 /* y[i, :dim] = sum_t coef[t] * src[t][i, :dim]  for i < n_rows, terms added in index order, each product
  * rounded before its add -- the order of the reference's running layer sum `out = out + x * alpha`
  * (src/lightgcn.py:93,97).  `src`, `src_stride`, `coef` are HOST arrays of n_terms (1..LGC_MAX_TERMS) entries;

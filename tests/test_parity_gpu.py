@@ -722,3 +722,59 @@ def test_recommendk_frame_is_upstreams_frame(device):
     users_e, items_e = torch.split(emb, [g.n_users, g.n_items])
     assert_topk_exact_up_to_ties(np.array(frame['top_rlvnt_itm'].tolist()), top.numpy(),
                                  ((users_e[users] @ items_e.t()) * (1 - seen)).numpy())
+
+
+@pytest.mark.parametrize("dim,layers", [(64, 3), (90, 5), (16, 1), (64, 0)])
+def test_seeded_backward_equals_the_dense_backward_and_the_oracle(device, dim, layers, monkeypatch):
+    """LightGCN.forward as one autograd node whose backward starts from the <= 2M seed rows
+    (lgc_seed_push for the first item step, no dense zero-filled gradient) vs the dense two-node path and the oracle's
+    autograd; duplicated nodes in the label pairs, an out-of-range pair, and the regulariser's dense gradient added."""
+    from gnn_ecommerce_amd import propagate
+    g, ei, ew = small_graph(13, 900, 140, 9000)
+    n = g.num_nodes
+    gen = torch.Generator().manual_seed(5)
+    b = 48
+    users = torch.randint(0, g.n_users, (b,), generator=gen)
+    users[:6] = users[0]                                              # one user in several pairs
+    pos = torch.randint(0, g.n_items, (b,), generator=gen) + g.n_users
+    neg = torch.randint(0, g.n_items, (b,), generator=gen) + g.n_users
+    neg[3] = pos[3]
+    labels = oracle.batch_pos_neg_edges(users, pos, neg)
+    w0 = synth.xavier_table(n, dim, 2)
+    alpha = oracle.default_alpha(layers)
+
+    def run(factor):
+        monkeypatch.setattr(propagate, "SEED_ROWS_FACTOR", factor)
+        model = lg.LightGCN(n, dim, layers)
+        model.load_state_dict({"alpha": alpha, "embedding.weight": w0})
+        model.to(device)
+        out = model(ei.to(device), labels.to(device), ew.to(device))
+        loss = model.recommendation_loss(out[:b], out[b:], 0) * b \
+            + oracle.regularization_loss(model.embedding.weight, b, users.to(device), pos.to(device), neg.to(device), 1e-4)
+        loss.backward()
+        return out.detach().cpu(), model.embedding.weight.grad.cpu(), out.grad_fn
+
+    s_out, s_grad, s_fn = run(0)                     # seeded
+    d_out, d_grad, d_fn = run(10 ** 9)               # dense
+    assert "ScoresFromTable" in type(s_fn).__name__ and "ScoresFromTable" not in type(d_fn).__name__
+    assert torch.equal(s_out, d_out)
+    assert rel_fro(s_grad, d_grad) <= 2e-6 and worst_row_rel(s_grad, d_grad) <= TOL
+    wr = w0.clone().requires_grad_(True)
+    _, _, _, ref_loss = oracle.train_step_loss(wr, alpha, ei, ew, users, pos, neg, layers, 1e-4)
+    ref_loss.backward()
+    assert rel_fro(s_grad, wr.grad) <= TOL
+    # an out-of-range pair scores NaN, raises at the check, and contributes no gradient
+    bad = labels.clone()
+    bad[1, 5] = n + 3
+    monkeypatch.setattr(propagate, "SEED_ROWS_FACTOR", 0)
+    model = lg.LightGCN(n, dim, layers)
+    model.load_state_dict({"alpha": alpha, "embedding.weight": w0})
+    model.to(device)
+    out = model(ei.to(device), bad.to(device), ew.to(device))
+    assert torch.isnan(out[5]) and not torch.isnan(out[6])
+    keep = torch.ones(2 * b, dtype=torch.bool)
+    keep[5] = False
+    out[keep.to(device)].sum().backward()
+    assert torch.isfinite(model.embedding.weight.grad).all()
+    with pytest.raises(IndexError):
+        lg.check_index_status()

@@ -14,12 +14,13 @@ ap.add_argument("--steps", type=int, default=10); ap.add_argument("--batch", typ
 ap.add_argument("--sampler", choices=["uniform", "device", "python"], default="uniform",
                 help="uniform: seeded uniform triples (SURVEY 8d); device: TripleSampler (batch_loader contract on "
                      "the GPU); python: the oracle restatement of the reference's batch_loader on the host")
+ap.add_argument("--adam", choices=["default", "fused"], default="default", help="torch.optim.Adam(fused=...)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 g = synth.make_bipartite(**synth.CONFIG_COSMETICS, seed=0)
 ei, ew = g.coo(dev)
 model = lg.LightGCN(g.num_nodes, args.dim, args.layers).to(dev)
-opt = torch.optim.Adam(model.parameters(), 0.005)
+opt = torch.optim.Adam(model.parameters(), 0.005, fused=(args.adam == 'fused'))
 gen = torch.Generator().manual_seed(0)
 purchase = g.weight == 1.0                      # positives = purchases, as pos_item_list (src/utils_v2.py:64-73)
 pu, pi = g.user[purchase], g.item[purchase] + g.n_users
@@ -62,4 +63,4 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(args.steps): vals = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / args.steps
 print(json.dumps({"metric": "training steps/s (fwd+bwd+Adam, B=%d)" % args.batch, "value": 1 / dt, "ms_per_step": dt * 1e3,
-                  "dim": args.dim, "layers": args.layers, "sampler": args.sampler, "loss": vals[2]}))
+                  "dim": args.dim, "layers": args.layers, "sampler": args.sampler, "adam": args.adam, "loss": vals[2]}))
