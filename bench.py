@@ -33,7 +33,10 @@ import torch
 import torch.distributed as dist
 
 LAYERS, DIM, SEED = 3, 64, 0
-CPU_THREADS_DEFAULT = 32  # fastest setting measured on the GPU box's 2 x EPYC 9575F host
+# Thread sweep of the CPU baseline on the GPU box's host (2 x EPYC 9575F, 256 hardware threads visible; round 1,
+# gpurun_out/cpu_threads.log): 8 -> 7.5, 16/32 -> 7.9, 64 -> 8.5, 128 -> 6.7, 256 -> 3.5 M edges/s per layer.
+# The route is memory-bound; 64 threads is the fastest setting, so that is the default (capped by the cores present).
+CPU_THREADS_DEFAULT = 64
 HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
 
 
@@ -52,9 +55,18 @@ def parse():
     return ap.parse_args()
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            names = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")]
+        return f"{names[0]} ({len(names)} hardware threads visible)" if names else "unknown CPU"
+    except OSError:
+        return "unknown CPU"
+
+
 def cpu_baseline(graph, layers, dim, threads=0):
-    """Reference-semantics CPU path on a bounded sample: ONE full K-layer propagate of the same graph
-    after a one-layer warm-up (about 4 layer-times of CPU work)."""
+    """Reference-semantics CPU path on a bounded sample (SURVEY.md 8d protocol): the full K-layer propagate of the
+    same graph, one warm-up layer then best of 3 passes (about 25 s of host time at full size)."""
     from oracle import lightgcn_oracle as oracle
     from gnn_ecommerce_amd import synth
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
@@ -62,14 +74,18 @@ def cpu_baseline(graph, layers, dim, threads=0):
     torch.set_num_threads(cores)
     ei, ew = graph.coo()
     w0 = synth.xavier_table(graph.num_nodes, dim, SEED)
+    times = []
     with torch.no_grad():
         oracle.lgconv(w0, ei, ew)                     # warm-up (allocator, thread pool)
-        t0 = time.perf_counter()
-        oracle.get_embedding(w0, oracle.default_alpha(layers), ei, ew, layers)
-        dt = time.perf_counter() - t0
+        for _ in range(3):
+            t0 = time.perf_counter()
+            oracle.get_embedding(w0, oracle.default_alpha(layers), ei, ew, layers)
+            times.append(time.perf_counter() - t0)
+    dt = min(times)
     out = {"value": graph.nnz * layers / dt, "unit": "edges/s", "cores": cores, "kind": "port",
-           "sample": f"1 full {layers}-layer get_embedding of the same graph ({graph.nnz} edges, D={dim}), "
-                     f"torch {torch.__version__} CPU fp32, {dt:.2f} s, after a 1-layer warm-up"}
+           "sample": f"full {layers}-layer get_embedding of the same graph ({graph.nnz} edges, D={dim}), torch "
+                     f"{torch.__version__} CPU fp32 on {cpu_model()}, {cores} threads, best of 3 passes "
+                     f"({', '.join('%.2f' % t for t in times)} s) after a 1-layer warm-up"}
     # a STRONGER comparator that is not the reference's route -- torch's own CSR SpMM (MKL)
     # on the same normalised values, graph conversion excluded, K hops after one warm-up hop.
     with torch.no_grad():
@@ -84,6 +100,16 @@ def cpu_baseline(graph, layers, dim, threads=0):
                                   "value": graph.nnz * layers / dt2, "unit": "edges/s", "cores": cores,
                                   "seconds": round(dt2, 3)}
     return out
+
+
+def kernel_source_hash() -> str:
+    """sha256 over the files that decide which bytes a hop moves: the kernels and the work plans."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ("gnn-ecommerce_amd/csrc/lgconv_hip.hip", "gnn-ecommerce_amd/graph.py", "gnn-ecommerce_amd/propagate.py"):
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def self_launch(n: int) -> int:
@@ -173,11 +199,16 @@ def main():
     bmin = synth.algorithmic_bytes_per_layer(n, nnz, args.dim)
     achieved = bmin / hop_mean_s if hop_mean_s > 0 else 0.0
     if rank == 0:
-        traffic = None
+        # HBM bytes per hop come from separate rocprofv3 PMC passes (profiles/collect.sh); the figure is only quoted
+        # while the kernel source it was measured on is the one running now, otherwise null
+        traffic, traffic_note = None, "no PMC measurement for this kernel source (run profiles/collect.sh)"
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if world == 1 and os.path.isfile(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get(f"{args.config}_d{args.dim}")
+                tj = json.load(f)
+            if tj.get("kernel_source_sha256") == kernel_source_hash():
+                traffic = tj.get(f"{args.config}_d{args.dim}")
+                traffic_note = tj.get("source", "")
         line = {
             "metric": "edges propagated/sec per LGConv layer",
             "value": nnz * args.layers * args.steps / elapsed,
@@ -195,8 +226,9 @@ def main():
                        "parallelism": parallelism, "seed": SEED,
                        "graph_build_s": round(t_build, 3), "synth_gen_s": round(t_gen, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": traffic,
-                         "kernel": "one hop = one LGConv layer: k_spmm_hop (chunk + row parts) + k_spmm_combine per operator half",
+                         "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_note,
+                         "kernel": "one hop = one LGConv layer: item step k_sweep + k_sweep_combine, user step "
+                                   "k_rows_tile_dpp<8|16|32> + k_spmm_hop (rows > 32 entries)",
                          "algorithmic_bytes_per_launch": bmin, "launch_ms": hop_mean_s * 1e3,
                          "launches_timed": len(hop_ms)},
         }

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
+from ctypes import CFUNCTYPE, POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 from typing import Optional
 
 import torch
@@ -17,7 +17,7 @@ import torch
 LIB_NAME = "liblgconv_hip.so"
 # LGCN_LIB_PATH selects another build of the SAME library (A/B kernel experiments); never a fallback.
 LIB_PATH = os.environ.get("LGCN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", LIB_NAME)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # status bits (include/lgconv_hip.h)
 ST_INDEX_OOB = 1
@@ -35,6 +35,29 @@ class SweepDims(Structure):
                 ("n_rows", c_int32), ("reserved", c_int32),
                 ("n_waves", c_int64), ("n_slabs", c_int64), ("n_slots", c_int64), ("n_entries", c_int64),
                 ("n_steps", c_int64), ("n_padding", c_int64)]
+
+
+class TileClassC(Structure):
+    """lgc_tile_class"""
+    _fields_ = [("order", c_void_p), ("meta", c_void_p), ("slab", c_void_p), ("n_tiles", c_int32), ("width", c_int32)]
+
+
+class SweepArraysC(Structure):
+    """lgc_sweep_arrays"""
+    _fields_ = [("slabs", c_void_p), ("wave_slab_ptr", c_void_p), ("wave_npieces", c_void_p), ("piece_slot", c_void_p),
+                ("multi", c_void_p), ("multi_wide", c_void_p), ("partials", c_void_p), ("n_waves", c_int64),
+                ("row_cap", c_int32), ("n_rows", c_int32), ("n_wide", c_int32), ("reserved", c_int32)]
+
+
+class OperatorC(Structure):
+    """lgc_operator"""
+    _fields_ = [("rowptr", c_void_p), ("entries", c_void_p), ("chunks", c_void_p), ("multi", c_void_p),
+                ("partials", c_void_p), ("sweep", POINTER(SweepArraysC)), ("tiles", TileClassC * 3),
+                ("row_begin", c_int32), ("row_end", c_int32), ("short_max", c_int32), ("n_chunks", c_int32),
+                ("n_multi", c_int32), ("n_tile_classes", c_int32), ("tiles_per_wave", c_int32), ("reserved", c_int32)]
+
+
+EXCHANGE_FN = CFUNCTYPE(c_int, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p)   # lgc_exchange_fn
 
 
 # symbol -> (restype, argtypes); tests check every name against the header and the .so
@@ -60,6 +83,10 @@ SIGNATURES = {
     "lgc_spmm_sweep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int32, c_void_p,
                                c_int32, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float, c_float,
                                c_int32, c_void_p]),
+    "lgc_apply": (c_int, [POINTER(OperatorC), c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float, c_float,
+                          c_int32, c_void_p]),
+    "lgc_hop_exchange": (c_int, [POINTER(OperatorC), POINTER(OperatorC), c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+                                 c_int64, c_float, c_float, c_int32, c_int32, c_int32, EXCHANGE_FN, c_void_p, c_void_p]),
     "lgc_seed_push": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p, c_int64, c_int32,
                               c_void_p]),
     "lgc_lincomb": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p]),

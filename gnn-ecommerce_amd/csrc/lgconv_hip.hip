@@ -1720,6 +1720,48 @@ int lgc_spmm_sweep(const uint32_t *slabs, const int32_t *wave_slab_ptr, const in
     return (int)hipGetLastError();
 }
 
+int lgc_apply(const lgc_operator *op, int64_t table_rows, const float *x, int64_t x_stride, float *y, int64_t y_stride,
+              const float *r, int64_t r_stride, float a, float b, int32_t dim, void *stream) {
+    if (!op || op->n_tile_classes < 0 || op->n_tile_classes > 3) return LGC_E_INVAL;
+    if (op->sweep && lgc_sweep_ok(dim, table_rows, x_stride)) {
+        const lgc_sweep_arrays *sw = op->sweep;
+        return lgc_spmm_sweep(sw->slabs, sw->wave_slab_ptr, sw->wave_npieces, sw->piece_slot, sw->n_waves, sw->row_cap,
+                              sw->multi, sw->n_rows, sw->multi_wide, sw->n_wide, sw->partials, table_rows, x, x_stride, y,
+                              y_stride, r, r_stride, a, b, dim, stream);
+    }
+    const bool tiled = op->n_tile_classes > 0 && dim >= 4;
+    if (!tiled || op->n_chunks > 0) {   // long rows first (they run longest); with tiles the row part gets an empty range
+        const int rc = lgc_spmm(op->rowptr, op->entries, op->row_begin, tiled ? op->row_begin : op->row_end, op->short_max,
+                                op->chunks, op->n_chunks, op->multi, op->n_multi, op->partials, table_rows, x, x_stride, y,
+                                y_stride, r, r_stride, a, b, dim, stream);
+        if (rc != 0) return rc;
+    }
+    if (tiled) {
+        for (int c = 0; c < op->n_tile_classes; ++c) {
+            const lgc_tile_class &tc = op->tiles[c];
+            const int rc = lgc_spmm_tiles(tc.order, tc.meta, tc.slab, tc.n_tiles, tc.width,
+                                          op->tiles_per_wave > 0 ? op->tiles_per_wave : 1, 1, table_rows, x, x_stride, y,
+                                          y_stride, r, r_stride, a, b, dim, stream);
+            if (rc != 0) return rc;
+        }
+    }
+    return 0;
+}
+
+int lgc_hop_exchange(const lgc_operator *item_op, const lgc_operator *user_op, int64_t table_rows, const float *x,
+                     int64_t x_stride, float *y, int64_t y_stride, const float *r, int64_t r_stride, float a, float b,
+                     int32_t dim, int32_t exchange_row_begin, int32_t exchange_rows, lgc_exchange_fn exchange, void *user,
+                     void *stream) {
+    if (!item_op || !user_op || !exchange || exchange_row_begin < 0 || exchange_rows < 0 ||
+        (int64_t)exchange_row_begin + exchange_rows > table_rows)
+        return LGC_E_INVAL;
+    int rc = lgc_apply(item_op, table_rows, x, x_stride, y, y_stride, r, r_stride, a, b, dim, stream);
+    if (rc != 0) return rc;
+    rc = exchange(y + (int64_t)exchange_row_begin * y_stride, exchange_rows, y_stride, dim, stream, user);
+    if (rc != 0) return rc;
+    return lgc_apply(user_op, table_rows, x, x_stride, y, y_stride, r, r_stride, a, b, dim, stream);
+}
+
 int lgc_seed_push(const int32_t *rowptr, const lgc_entry *entries, const int64_t *seed_rows, const float *seed_vals,
                   int64_t n_seed, int64_t n_rows, float scale, float *y, int64_t y_stride, int32_t dim, void *stream_) {
     if (!rowptr || !y || n_seed < 0 || n_rows < 0 || dim < 1 || dim > 256 || y_stride < dim) return LGC_E_INVAL;

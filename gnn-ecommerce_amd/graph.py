@@ -278,6 +278,7 @@ class Operator:
     _sweep: Optional[SweepPlan] = None
     _tiles: Optional[List[TileClass]] = None
     _partials: Dict[int, Tensor] = field(default_factory=dict)
+    _c_structs: Dict[tuple, list] = field(default_factory=dict)
 
     @classmethod
     def build(cls, n_rows: int, rowptr: Tensor, entries: Tensor, row_begin: int, row_end: int,
@@ -337,8 +338,43 @@ class Operator:
     def columns(self) -> Tensor:
         return self.entries[:, 0]
 
+    def c_struct(self, dim: int, sweep: bool) -> "_native.OperatorC":
+        """The operator as the C ABI's ``lgc_operator`` (device pointers of tensors this object keeps alive), cached per
+        embedding width because the scratch buffers are per width."""
+        import ctypes
+        key = (dim, sweep)
+        got = self._c_structs.get(key)
+        if got is not None:
+            return got[0]
+        p = self.plan
+        c = _native.OperatorC()
+        c.rowptr, c.entries = _native.ptr(self.rowptr), _native.ptr(self.entries)
+        c.chunks = _native.ptr(p.chunks) if p.n_chunks else None
+        c.multi = _native.ptr(p.multi) if p.n_multi else None
+        c.partials = _native.ptr(self.partials(dim))
+        c.row_begin, c.row_end, c.short_max, c.n_chunks, c.n_multi = p.row_begin, p.row_end, p.short_max, p.n_chunks, p.n_multi
+        c.tiles_per_wave = TILES_PER_WAVE
+        keep = [c]
+        if self.tiled and dim >= 4:
+            for i, tc in enumerate(self.tiles):
+                c.tiles[i] = _native.TileClassC(_native.ptr(tc.order), _native.ptr(tc.meta), _native.ptr(tc.slab), tc.n_tiles,
+                                                tc.width)
+            c.n_tile_classes = len(self.tiles)
+        if sweep:
+            sw = self.sweep
+            sc = _native.SweepArraysC(_native.ptr(sw.slabs), _native.ptr(sw.wave_slab_ptr), _native.ptr(sw.wave_npieces),
+                                      _native.ptr(sw.piece_slot), _native.ptr(sw.multi) if sw.multi.size(0) else None,
+                                      _native.ptr(sw.multi_wide) if sw.multi_wide.size(0) else None,
+                                      _native.ptr(sw.partials(dim)), sw.dims["n_waves"], sw.dims["row_cap"], sw.multi.size(0),
+                                      sw.multi_wide.size(0), 0)
+            c.sweep = ctypes.pointer(sc)
+            keep.append(sc)
+        self._c_structs[key] = keep
+        return c
+
     def apply(self, x: Tensor, out: Tensor, a: float = 1.0, r: Optional[Tensor] = None, b: float = 0.0) -> Tensor:
-        """out[row] = a * (A x)[row] + b * r[row] for the rows of the plan.  Launches on the current stream."""
+        """out[row] = a * (A x)[row] + b * r[row] for the rows of the plan: one ``lgc_apply`` on the current stream."""
+        import ctypes
         _check_table(x, "x")
         _check_table(out, "out")
         dim = x.size(1)
@@ -351,41 +387,14 @@ class Operator:
         lib = _native.load()
         if not lib.lgc_dim_ok(dim):
             raise _native.NativeLibraryError(f"embedding width {dim} is not supported by the HIP kernels")
-        p = self.plan
-        partials = self.partials(dim)
         table_rows = min(x.size(0), out.size(0))
-        tiled = self.tiled and dim >= 4
-        r_ptr, r_stride = _native.ptr(r), (0 if r is None else r.stride(0))
-        stream = _native.stream_of(x.device)
-        if self.sweep_cols is not None and lib.lgc_sweep_ok(dim, table_rows, x.stride(0)):
-            sw = self.sweep
-            with torch.cuda.device(x.device):
-                code = lib.lgc_spmm_sweep(
-                    _native.ptr(sw.slabs), _native.ptr(sw.wave_slab_ptr), _native.ptr(sw.wave_npieces),
-                    _native.ptr(sw.piece_slot), sw.dims["n_waves"], sw.dims["row_cap"],
-                    _native.ptr(sw.multi) if sw.multi.size(0) else None, sw.multi.size(0),
-                    _native.ptr(sw.multi_wide) if sw.multi_wide.size(0) else None, sw.multi_wide.size(0),
-                    _native.ptr(sw.partials(dim)), table_rows, _native.ptr(x), x.stride(0),
-                    _native.ptr(out), out.stride(0), r_ptr, r_stride, float(a), float(b), dim, stream)
-            _native.check(code, "lgc_spmm_sweep")
-            return out
+        sweep = self.sweep_cols is not None and bool(lib.lgc_sweep_ok(dim, table_rows, x.stride(0)))
+        c = self.c_struct(dim, sweep)
         with torch.cuda.device(x.device):
-            # long rows first (they run longest); with tiles the row part of lgc_spmm gets an empty range
-            if not tiled or p.n_chunks:
-                code = lib.lgc_spmm(
-                    _native.ptr(self.rowptr), _native.ptr(self.entries), p.row_begin, p.row_begin if tiled else p.row_end,
-                    p.short_max, _native.ptr(p.chunks) if p.n_chunks else None, p.n_chunks,
-                    _native.ptr(p.multi) if p.n_multi else None, p.n_multi, _native.ptr(partials), table_rows,
-                    _native.ptr(x), x.stride(0), _native.ptr(out), out.stride(0), r_ptr, r_stride, float(a), float(b),
-                    dim, stream)
-                _native.check(code, "lgc_spmm")
-            if tiled:
-                for tc in self.tiles:
-                    code = lib.lgc_spmm_tiles(
-                        _native.ptr(tc.order), _native.ptr(tc.meta), _native.ptr(tc.slab), tc.n_tiles, tc.width,
-                        TILES_PER_WAVE, 1, table_rows, _native.ptr(x), x.stride(0), _native.ptr(out), out.stride(0),
-                        r_ptr, r_stride, float(a), float(b), dim, stream)
-                    _native.check(code, "lgc_spmm_tiles")
+            code = lib.lgc_apply(ctypes.byref(c), table_rows, _native.ptr(x), x.stride(0), _native.ptr(out), out.stride(0),
+                                 _native.ptr(r), 0 if r is None else r.stride(0), float(a), float(b), dim,
+                                 _native.stream_of(x.device))
+        _native.check(code, "lgc_apply")
         return out
 
 

@@ -81,6 +81,9 @@ class HipOps:
     def apply(self, op: Operator, x: Tensor, out: Tensor, a: float, r: Optional[Tensor], b: float) -> None:
         op.apply(x, out, a=a, r=r, b=b)
 
+    def lincomb(self, y: Tensor, terms) -> None:
+        _native.lincomb(y, terms)
+
 
 class PartitionedPropagator:
     """K-hop propagate + layer sum for rank ``rank`` of ``world`` (see module docstring)."""
@@ -115,6 +118,7 @@ class PartitionedPropagator:
         self._keep = (full, local)
         self._coo = (edge_index, full.edge_values)
         self._transposed = None
+        self._table_cache = {}
 
     # -- hops ----------------------------------------------------------------------------------
     # A hop has two local pieces and one exchange:
@@ -160,51 +164,88 @@ class PartitionedPropagator:
                                 self.ops.restrict(g_item.transpose_op, nu, n, ITEM_SHORT_MAX), g_user, g_item)
         return self._transposed[0], self._transposed[1]
 
+    def _lincomb(self, y: Tensor, terms) -> None:
+        lc = getattr(self.ops, "lincomb", None)
+        if lc is not None:
+            lc(y, terms)
+        else:                                                   # test doubles without a lincomb: the same sum in torch
+            acc = terms[0][1] * terms[0][0]
+            for c, t in terms[1:]:
+                acc = acc + t * c
+            y.copy_(acc)
+
+    def _tables(self, like: Tensor, count: int, tag) -> List[Tensor]:
+        """``count`` internal [N, D] tables, allocated once per (width, count, direction) and reused by every call:
+        no allocation inside the hop loop."""
+        key = (like.size(1), like.dtype, like.device, count, tag)
+        got = self._table_cache.get(key)
+        if got is None:
+            got = [torch.empty_like(like) for _ in range(count)]
+            self._table_cache[key] = got
+        return got
+
     def propagate_sum(self, x0: Tensor, alphas: Sequence[float], transpose: bool = False,
                       zero_foreign_rows: bool = False) -> Tensor:
-        """Horner form of sum_l alpha_l A^l x0 (see propagate.py); valid rows of the result: own users + items.
-        ``transpose``: the same with A^T (the backward pass).  ``zero_foreign_rows``: other ranks' user rows of
-        the result are zero instead of undefined."""
+        """sum_l alpha_l A^l x0 on this rank's rows (own users + all items), in the bipartite evaluation of
+        propagate.bipartite_sum: with x_l = A^l x0,
+            x_l[items]  = all-reduce( item step over OWN users of x_{l-1} )          l = 1 .. K
+            x_l[users]  = user step of x_{l-1}[items]   (own users)                  l = 1 .. K-1
+            out[users]  = alpha_0 x0[users] + user step of ( sum_{l>=1} alpha_l x_{l-1}[items] )
+            out[items]  = sum_l alpha_l x_l[items]
+        so no hop reads an epilogue row except the last user step, and the K-th user table is never written.
+        The all-reduce of layer l is started right after its item step and waited for only where x_l[items] is first
+        read -- the user step of layer l+1 (or the final sums) -- i.e. it is in flight across one user step and the next
+        item step.  ``transpose``: the same with A^T (the backward pass).  ``zero_foreign_rows``: other ranks' user rows
+        of the result are zero instead of undefined."""
         from . import propagate
         k = len(alphas) - 1
         if k == 0:
             return x0 * alphas[0]
         x0 = x0.contiguous()
+        nu = self.n_users
         user_op, item_op = self._transposed_ops() if transpose else (self.user_op, self.item_op)
-        new_table = torch.zeros_like if zero_foreign_rows else torch.empty_like
         log = propagate.HOP_EVENT_LOG if x0.is_cuda else None
-        # hop j (j = 0 .. k-1) maps h_in -> h_out with epilogue (a_j, b_j, r = x0)
-        coef = [(alphas[k], alphas[k - 1])] + [(1.0, alphas[layer]) for layer in range(k - 2, -1, -1)]
-        h_in, h_out = x0, (new_table(x0) if k == 1 else torch.empty_like(x0))
-        pending = None                                   # exchange of the previous hop's item block
+        tables = [x0] + self._tables(x0, k + 1, transpose)          # x_1 .. x_K, and the mix table
+        mix = tables.pop()
+        out = torch.zeros_like(x0) if zero_foreign_rows else torch.empty_like(x0)
+        pending = [None] * (k + 1)                                   # all-reduce of x_l[items]
         marks = []
-        for j, (a, b) in enumerate(coef):
+        for layer in range(1, k + 1):
             if log is not None:
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record()
                 marks.append(ev)
-            work = self._item_step(item_op, h_in, h_out, a, x0, b)   # needs only OWN user rows of h_in
-            self._finish_items(pending)                  # now the previous hop's item block is needed
-            self.ops.apply(user_op, h_in, h_out, a, x0, b)
-            pending = work
-            if j + 1 < k:
-                h_in, h_out = h_out, (new_table(x0) if j + 2 == k else torch.empty_like(x0))
-        self._finish_items(pending)
+            prev, cur = tables[layer - 1], tables[layer]
+            pending[layer] = self._item_step(item_op, prev, cur, 1.0, None, 0.0)     # needs only OWN user rows of x_{l-1}
+            self._finish_items(pending[layer - 1])                                   # x_{l-1}[items] is read from here on
+            if layer < k:
+                self.ops.apply(user_op, prev, cur, 1.0, None, 0.0)
+            else:
+                self._lincomb(mix[nu:], [(alphas[l], tables[l - 1][nu:]) for l in range(1, k + 1)])
+                self.ops.apply(user_op, mix, out, 1.0, x0, alphas[0])
+                self._finish_items(pending[k])
+                self._lincomb(out[nu:], [(alphas[l], tables[l][nu:]) for l in range(0, k + 1)])
         if log is not None:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
             marks.append(ev)
             log.extend(zip(marks[:-1], marks[1:]))
-        return h_out
+        return out
 
     def gather_users(self, table: Tensor) -> Tensor:
-        """Fill every rank's user rows of ``table`` from their owners (all ranks end with the full table)."""
+        """Fill every rank's user rows of ``table`` from their owners (all ranks end with the full table): ONE
+        all-gather of the ranges padded to the longest one."""
         if self.world == 1:
             return table
+        longest = max(hi - lo for lo, hi in self.ranges)
+        dim = table.size(1)
+        mine = torch.zeros((longest, dim), dtype=table.dtype, device=table.device)
+        mine[: self.u1 - self.u0] = table[self.u0:self.u1]
+        everyone = torch.empty((self.world * longest, dim), dtype=table.dtype, device=table.device)
+        dist.all_gather_into_tensor(everyone, mine, group=self.group)
         for owner, (lo, hi) in enumerate(self.ranges):
-            if hi > lo:
-                dist.broadcast(table[lo:hi], src=dist.get_global_rank(self.group, owner) if self.group else owner,
-                               group=self.group)
+            if owner != self.rank and hi > lo:
+                table[lo:hi] = everyone[owner * longest: owner * longest + (hi - lo)]
         return table
 
 

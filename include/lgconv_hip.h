@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LGC_ABI_VERSION 5
+#define LGC_ABI_VERSION 6
 
 /* argument errors (negative return values) */
 #define LGC_E_INVAL      (-1)  /* null pointer, negative size, bad flag                    */
@@ -212,6 +212,60 @@ int lgc_spmm_sweep(const uint32_t *slabs, const int32_t *wave_slab_ptr, const in
                    const int32_t *piece_slot, int64_t n_waves, int32_t row_cap, const lgc_multi_row *multi,
                    int32_t n_rows, const lgc_multi_row *multi_wide, int32_t n_wide, float *partials, int64_t table_rows, const float *x, int64_t x_stride, float *y,
                    int64_t y_stride, const float *r, int64_t r_stride, float a, float b, int32_t dim, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * One operator half as a single argument, and the per-hop exchange hook.
+ *
+ * lgc_operator gathers everything one `y[rows] = a * A[rows, :] x + b * r[rows]` needs -- the chunk plan of
+ * lgc_spmm, the tile classes of lgc_spmm_tiles and, when the half qualifies, the band-sweep arrays -- so that a
+ * host applies it with ONE call (lgc_apply picks the path exactly as the separate entry points would:
+ * sweep if `sweep` is set and lgc_sweep_ok(dim, table_rows, x_stride); else chunks + tiles; tiles need dim >= 4,
+ * narrower tables take lgc_spmm's row part over [row_begin, row_end)).
+ *
+ * lgc_hop_exchange is one LGConv layer (src/lightgcn.py:96) of a user|item graph PARTITIONED over several devices
+ * (SURVEY.md 8e): item step (partial sums of all item rows from this rank's own users) -> `exchange(block, rows,
+ * row_stride, dim, stream, user)` -> user step (this rank's users from the replicated, now reduced, item rows).
+ * The callback must leave the SUM over ranks in `block` (y rows [exchange_row_begin, +exchange_rows), row stride
+ * y_stride floats) in stream order -- e.g. ncclAllReduce(block, block, rows * row_stride, ncclFloat, ncclSum, comm,
+ * stream) when y_stride == dim -- and return 0; it is the only place where the library needs the host's
+ * communicator, which it never sees.  A non-zero return aborts the hop and is handed back.
+ */
+typedef struct lgc_tile_class {
+    const int32_t   *order;      /* device, [n_tiles * R]            */
+    const int32_t   *meta;       /* device, [n_tiles] or NULL        */
+    const lgc_entry *slab;       /* device, lgc_build_tiles layout   */
+    int32_t n_tiles, width;
+} lgc_tile_class;
+
+typedef struct lgc_sweep_arrays {
+    const uint32_t *slabs;
+    const int32_t  *wave_slab_ptr, *wave_npieces, *piece_slot;
+    const lgc_multi_row *multi, *multi_wide;
+    float   *partials;           /* [n_slots, dim] scratch            */
+    int64_t  n_waves;
+    int32_t  row_cap, n_rows, n_wide, reserved;
+} lgc_sweep_arrays;
+
+typedef struct lgc_operator {
+    const int32_t   *rowptr;
+    const lgc_entry *entries;
+    const lgc_chunk *chunks;
+    const lgc_multi_row *multi;
+    float   *partials;           /* scratch of the chunk plan, [n_slots, dim] or NULL */
+    const lgc_sweep_arrays *sweep;   /* HOST pointer or NULL */
+    lgc_tile_class tiles[3];
+    int32_t row_begin, row_end, short_max, n_chunks, n_multi, n_tile_classes, tiles_per_wave, reserved;
+} lgc_operator;
+
+int lgc_apply(const lgc_operator *op, int64_t table_rows, const float *x, int64_t x_stride, float *y, int64_t y_stride,
+              const float *r, int64_t r_stride, float a, float b, int32_t dim, void *stream);
+
+typedef int (*lgc_exchange_fn)(float *block, int64_t rows, int64_t row_stride, int32_t dim, void *stream, void *user);
+
+int lgc_hop_exchange(const lgc_operator *item_op, const lgc_operator *user_op, int64_t table_rows, const float *x,
+                     int64_t x_stride, float *y, int64_t y_stride, const float *r, int64_t r_stride, float a, float b,
+                     int32_t dim, int32_t exchange_row_begin, int32_t exchange_rows, lgc_exchange_fn exchange,
+                     void *user, void *stream);
 
 /* Seeded transpose step (first hop of the backward pass, loss.backward() at src/train_lightgcn.py:146): the incoming
  * gradient of the scores of src/lightgcn.py:123-125 has non-zero rows only where a label pair points, so

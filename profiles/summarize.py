@@ -36,7 +36,7 @@ def counters(d, sub):
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
 
 
-HOP_KERNELS = ("k_spmm_hop", "k_spmm_rows", "k_spmm_chunks", "k_spmm_combine", "k_lincomb")
+HOP_KERNELS = ("k_spmm_hop", "k_spmm_combine", "k_lincomb", "k_rows_tile", "k_sweep", "k_combine_rows")
 
 
 def main(d, n_hops=0):
@@ -47,7 +47,7 @@ def main(d, n_hops=0):
             pmc[k].update(cs)
     res = {}
     for k, s in stats.items():
-        if not k.startswith("k_spmm") and not k.startswith("k_pair") and s["pct"] < 1.0:
+        if not k.startswith(HOP_KERNELS) and not k.startswith("k_pair") and s["pct"] < 1.0:
             continue
         e = dict(s)
         c = pmc.get(k, {})
@@ -68,6 +68,13 @@ def main(d, n_hops=0):
                 hop["kernel_us"] += e["calls"] * e["avg_us"] / n_hops
                 hop["hbm_bytes"] += e["calls"] * (e.get("fetch_bytes_x2", 0.0) + e.get("write_bytes", 0.0)) / n_hops
         res["per_hop"] = hop
+        # the figure bench.py quotes as roofline.traffic, stamped with the source it was measured on
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        try:
+            import bench
+            res["traffic_json"] = {"kernel_source_sha256": bench.kernel_source_hash(), "hbm_bytes_per_hop": int(hop["hbm_bytes"])}
+        except Exception as exc:  # pragma: no cover
+            res["traffic_json"] = {"error": str(exc)}
     print(json.dumps(res, indent=1))
 
 

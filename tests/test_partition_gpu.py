@@ -135,3 +135,53 @@ def test_two_ranks_training_step_matches_single_gpu(device):
     results = run_ranks(_train_worker, 2)
     for rank, r in results.items():
         assert r["bpr"] <= 1e-5 and r["reg"] <= 1e-5 and r["own"] <= 1e-5 and r["items"] <= 1e-5, (rank, r)
+
+
+def test_exchange_hook_of_the_c_abi_drives_a_partitioned_hop(device):
+    """include/lgconv_hip.h: lgc_hop_exchange = item step -> caller's exchange callback on the item block -> user step,
+    called through ctypes the way a non-Python host would, with the callback standing in for ncclAllReduce: it adds the
+    other rank's partial item block (both 'ranks' live in this process).  Result = the single-GPU hop on rank 0's rows."""
+    import ctypes
+    import gnn_ecommerce_amd as lg
+    from gnn_ecommerce_amd import _native, synth
+    from gnn_ecommerce_amd.partition import PartitionedPropagator
+    g = synth.make_bipartite(6000, 700, 50000, seed=5)
+    ei, ew = g.coo(device)
+    n, nu, dim = g.num_nodes, g.n_users, 64
+    x = synth.xavier_table(n, dim, 1, device)
+    r = synth.xavier_table(n, dim, 2, device)
+    want = lg.PropGraph(ei, ew, n).forward_op.apply(x, torch.empty_like(x), a=0.5, r=r, b=0.25)
+    pp = [PartitionedPropagator(ei, ew, nu, g.n_items, rank, 2) for rank in range(2)]
+    other = torch.zeros_like(x)
+    pp[1].item_op.apply(x, other, a=0.5)                       # rank 1's partial sums (rank 0 carries the epilogue term)
+    y = torch.full_like(x, float("nan"))
+    seen = {}
+
+    def exchange(block, rows, row_stride, d, stream, user):
+        seen.update(block=block, rows=rows, row_stride=row_stride, dim=d, stream=stream)
+        y[nu:] += other[nu:]                                   # in stream order on the current stream
+        return 0
+
+    cb = _native.EXCHANGE_FN(exchange)
+    lib = _native.load()
+    item_c, user_c = pp[0].item_op.c_struct(dim, False), pp[0].user_op.c_struct(dim, False)
+    code = lib.lgc_hop_exchange(ctypes.byref(item_c), ctypes.byref(user_c), n, x.data_ptr(), x.stride(0), y.data_ptr(),
+                                y.stride(0), r.data_ptr(), r.stride(0), 0.5, 0.25, dim, nu, g.n_items, cb, None,
+                                _native.stream_of(device))
+    assert code == 0
+    torch.cuda.synchronize()
+    assert seen["block"] == y[nu:].data_ptr() and seen["rows"] == g.n_items and seen["row_stride"] == dim and seen["dim"] == dim
+    lo, hi = pp[0].ranges[0]
+
+    def rel(a, b):
+        return ((a.double() - b.double()).norm() / b.double().norm()).item()
+
+    # rank 0 adds b * r to the item block it contributes (the item step of a rank-0 operator applies the epilogue)
+    assert rel(y[nu:], want[nu:]) <= 1e-5 and rel(y[lo:hi], want[lo:hi]) <= 1e-6
+    assert torch.isnan(y[hi:nu]).all()                         # the other rank's users are not touched
+    # a failing callback aborts the hop with its code
+    bad = _native.EXCHANGE_FN(lambda *a: 7)
+    assert lib.lgc_hop_exchange(ctypes.byref(item_c), ctypes.byref(user_c), n, x.data_ptr(), x.stride(0), y.data_ptr(),
+                                y.stride(0), None, 0, 1.0, 0.0, dim, nu, g.n_items, bad, None, _native.stream_of(device)) == 7
+    assert lib.lgc_hop_exchange(ctypes.byref(item_c), ctypes.byref(user_c), n, x.data_ptr(), x.stride(0), y.data_ptr(),
+                                y.stride(0), None, 0, 1.0, 0.0, dim, nu, g.n_items + 1, cb, None, None) == -1
