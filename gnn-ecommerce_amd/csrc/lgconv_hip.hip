@@ -809,6 +809,45 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, DEPTH
     }
 }
 
+// One launch per operator half and hop: chunk workgroups first (long rows run longest), then the tile classes.
+// Four separate launches cost a rank of an 8-way partition (~130 us of work per hop) a third of its time in launch
+// gaps; on one GPU it is a few percent.
+struct FusedArgs {
+    SpmmArgs sp;
+    const lgc_chunk *chunks;
+    float *partials;
+    TileArgs t[3];
+    int32_t n_chunks, chunk_blocks, n_classes;
+    int32_t width[3], blocks[3];
+};
+
+template <bool FAST>
+__global__ __launch_bounds__(kBlock) void k_apply_fused(FusedArgs f) {
+    int64_t b = blockIdx.x;
+    if (b < f.chunk_blocks) {
+        chunks_body<4>(f.sp, f.chunks, f.n_chunks, f.partials, b);
+        return;
+    }
+    b -= f.chunk_blocks;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (c >= f.n_classes) return;
+        if (b < f.blocks[c]) {
+            if constexpr (FAST) {
+                if (f.width[c] == 8) tiles_body_dpp<8, 1>(f.t[c], b);
+                else if (f.width[c] == 16) tiles_body_dpp<16, 1>(f.t[c], b);
+                else tiles_body_dpp<32, 2>(f.t[c], b);
+            } else {
+                if (f.width[c] == 8) tiles_body<8, 1>(f.t[c], b);
+                else if (f.width[c] == 16) tiles_body<16, 1>(f.t[c], b);
+                else tiles_body<32, 2>(f.t[c], b);
+            }
+            return;
+        }
+        b -= f.blocks[c];
+    }
+}
+
 // order + CSR -> tile layout: piece ((t*L + k)*R + s)*PPR + q holds entries k*Wk + 2q, +1 of the row in slot s of tile t
 __global__ void k_build_tiles(const int32_t *__restrict__ rowptr, const lgc_entry *__restrict__ entries,
                               const int32_t *__restrict__ order, int64_t n_slots, int32_t W, int32_t L,
@@ -1436,6 +1475,60 @@ int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry 
     return 0;
 }
 
+// Arguments of one tile class + whether the DPP/buffer fast path applies (see lgc_spmm_tiles).
+struct TilePrep {
+    TileArgs p;
+    bool fast;
+    int64_t blocks;
+};
+
+int prepare_tiles(TilePrep &out, const int32_t *order, const int32_t *meta, const lgc_entry *slab, int32_t n_tiles, int32_t width,
+                  int32_t tiles_per_wave, int32_t parts, int64_t table_rows, const float *x, int64_t x_stride, float *y,
+                  int64_t y_stride, const float *r, int64_t r_stride, float a, float b, int32_t dim) {
+    if (dim < 4 || dim > 256) return LGC_E_DIM;
+    if (!order || !slab || !x || !y || n_tiles < 0 || tiles_per_wave < 1 || (parts != 1 && parts != 2) || x == y)
+        return LGC_E_INVAL;
+    if (width != 8 && width != 16 && width != 32) return LGC_E_INVAL;
+    if (x_stride < dim || y_stride < dim || (r && r_stride < dim)) return LGC_E_INVAL;
+    if (!aligned_to(x, 4) || !aligned_to(y, 4) || (r && !aligned_to(r, 4)) || !aligned_to(slab, 16)) return LGC_E_ALIGN;
+    if (parts == 2 && (dim % 8 != 0)) return LGC_E_INVAL;
+    TileArgs p{};
+    p.order = order;
+    p.slab = reinterpret_cast<const u4 *>(slab);
+    p.x = x; p.y = y; p.r = r;
+    p.x_stride = x_stride; p.y_stride = y_stride; p.r_stride = r_stride;
+    p.a = a; p.b = b;
+    p.n_tiles = n_tiles; p.tiles_per_wave = tiles_per_wave;
+    p.parts = parts;
+    const int pd = dim / parts;
+    p.part_col[0] = 0; p.part_dim[0] = pd;
+    p.part_col[1] = pd; p.part_dim[1] = dim - pd;
+    p.lpr = (pd + 3) / 4;
+    p.wt_store = (table_rows * y_stride * 4 < (int64_t(1) << 32)) ? 1 : 0;
+    p.meta = meta;
+    const int64_t waves = ((int64_t)n_tiles + tiles_per_wave - 1) / tiles_per_wave;
+    out.blocks = (waves + 3) / 4;
+    // fast path: 16-lane rows, 24-bit row ids, 32-bit byte offsets, and the padding id 0xFFFFFF must fall outside
+    // every table so that the hardware's range check turns padding into "load zeros / drop the store"
+    auto table_bytes = [&](int64_t stride) { return ((table_rows - 1) * stride + dim) * 4; };
+    auto pad_is_oob = [&](int64_t stride) {
+        const uint32_t pad = (uint32_t)(0xFFFFFFull * (uint64_t)(stride * 4));
+        return stride * 4 < (1 << 24) && table_bytes(stride) < (int64_t(1) << 32) && (int64_t)pad >= table_bytes(stride);
+    };
+    out.fast = meta != nullptr && parts == 1 && dim >= 61 && dim <= 64 && table_rows > 0 && table_rows < 0xFFFFFF &&
+               pad_is_oob(x_stride) && pad_is_oob(y_stride) && (!r || pad_is_oob(r_stride)) &&
+               getenv("LGCN_NO_FAST_TILES") == nullptr;
+    if (out.fast) {
+        p.x_bytes = (uint32_t)table_bytes(x_stride);
+        p.y_bytes = (uint32_t)table_bytes(y_stride);
+        p.r_bytes = r ? (uint32_t)table_bytes(r_stride) : 0u;
+    } else if (parts == 2) {
+        out.blocks = ((out.blocks + 3) / 4) * 8;   // XCDs 0-3 and 4-7 each get ceil(blocks / 4) * 4 workgroups
+    }
+    out.p = p;
+    return 0;
+}
+
 }  // namespace
 
 // ========================================================================================
@@ -1568,54 +1661,22 @@ int lgc_build_tiles(const int32_t *rowptr, const lgc_entry *entries, const int32
 int lgc_spmm_tiles(const int32_t *order, const int32_t *meta, const lgc_entry *slab, int32_t n_tiles, int32_t width,
                    int32_t tiles_per_wave, int32_t parts, int64_t table_rows, const float *x, int64_t x_stride, float *y, int64_t y_stride,
                    const float *r, int64_t r_stride, float a, float b, int32_t dim, void *stream_) {
-    if (dim < 4 || dim > 256) return LGC_E_DIM;
-    if (!order || !slab || !x || !y || n_tiles < 0 || tiles_per_wave < 1 || (parts != 1 && parts != 2) || x == y)
-        return LGC_E_INVAL;
-    if (width != 8 && width != 16 && width != 32) return LGC_E_INVAL;
-    if (x_stride < dim || y_stride < dim || (r && r_stride < dim)) return LGC_E_INVAL;
-    if (!aligned_to(x, 4) || !aligned_to(y, 4) || (r && !aligned_to(r, 4)) || !aligned_to(slab, 16)) return LGC_E_ALIGN;
-    if (parts == 2 && (dim % 8 != 0)) return LGC_E_INVAL;
+    TilePrep tp;
+    const int rc = prepare_tiles(tp, order, meta, slab, n_tiles, width, tiles_per_wave, parts, table_rows, x, x_stride, y, y_stride,
+                                 r, r_stride, a, b, dim);
+    if (rc != 0) return rc;
     if (n_tiles == 0) return 0;
-    TileArgs p{};
-    p.order = order;
-    p.slab = reinterpret_cast<const u4 *>(slab);
-    p.x = x; p.y = y; p.r = r;
-    p.x_stride = x_stride; p.y_stride = y_stride; p.r_stride = r_stride;
-    p.a = a; p.b = b;
-    p.n_tiles = n_tiles; p.tiles_per_wave = tiles_per_wave;
-    p.parts = parts;
-    const int pd = dim / parts;
-    p.part_col[0] = 0; p.part_dim[0] = pd;
-    p.part_col[1] = pd; p.part_dim[1] = dim - pd;
-    p.lpr = (pd + 3) / 4;
-    p.wt_store = (table_rows * y_stride * 4 < (int64_t(1) << 32)) ? 1 : 0;
-    p.meta = meta;
-    const int64_t waves = ((int64_t)n_tiles + tiles_per_wave - 1) / tiles_per_wave;
-    int64_t blocks = (waves + 3) / 4;
     hipStream_t stream = as_stream(stream_);
-    // fast path: 16-lane rows, 24-bit row ids, 32-bit byte offsets, and the padding id 0xFFFFFF must fall outside
-    // every table so that the hardware's range check turns padding into "load zeros / drop the store"
-    auto table_bytes = [&](int64_t stride) { return ((table_rows - 1) * stride + dim) * 4; };
-    auto pad_is_oob = [&](int64_t stride) {
-        const uint32_t pad = (uint32_t)(0xFFFFFFull * (uint64_t)(stride * 4));
-        return stride * 4 < (1 << 24) && table_bytes(stride) < (int64_t(1) << 32) && (int64_t)pad >= table_bytes(stride);
-    };
-    const bool fast = meta != nullptr && parts == 1 && dim >= 61 && dim <= 64 && table_rows > 0 && table_rows < 0xFFFFFF &&
-                      pad_is_oob(x_stride) && pad_is_oob(y_stride) && (!r || pad_is_oob(r_stride)) &&
-                      getenv("LGCN_NO_FAST_TILES") == nullptr;
-    if (fast) {
-        p.x_bytes = (uint32_t)table_bytes(x_stride);
-        p.y_bytes = (uint32_t)table_bytes(y_stride);
-        p.r_bytes = r ? (uint32_t)table_bytes(r_stride) : 0u;
-        if (width == 8) hipLaunchKernelGGL((k_rows_tile_dpp<8, 1>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, p);
-        else if (width == 16) hipLaunchKernelGGL((k_rows_tile_dpp<16, 1>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, p);
-        else hipLaunchKernelGGL((k_rows_tile_dpp<32, 2>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, p);
-        return (int)hipGetLastError();
+    const dim3 grid((unsigned)tp.blocks);
+    if (tp.fast) {
+        if (width == 8) hipLaunchKernelGGL((k_rows_tile_dpp<8, 1>), grid, dim3(kBlock), 0, stream, tp.p);
+        else if (width == 16) hipLaunchKernelGGL((k_rows_tile_dpp<16, 1>), grid, dim3(kBlock), 0, stream, tp.p);
+        else hipLaunchKernelGGL((k_rows_tile_dpp<32, 2>), grid, dim3(kBlock), 0, stream, tp.p);
+    } else {
+        if (width == 8) hipLaunchKernelGGL((k_rows_tile<8, 1>), grid, dim3(kBlock), 0, stream, tp.p);
+        else if (width == 16) hipLaunchKernelGGL((k_rows_tile<16, 1>), grid, dim3(kBlock), 0, stream, tp.p);
+        else hipLaunchKernelGGL((k_rows_tile<32, 2>), grid, dim3(kBlock), 0, stream, tp.p);
     }
-    if (parts == 2) blocks = ((blocks + 3) / 4) * 8;   // XCDs 0-3 and 4-7 each get ceil(blocks / 4) * 4 workgroups
-    if (width == 8) hipLaunchKernelGGL((k_rows_tile<8, 1>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, p);
-    else if (width == 16) hipLaunchKernelGGL((k_rows_tile<16, 1>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, p);
-    else hipLaunchKernelGGL((k_rows_tile<32, 2>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, p);
     return (int)hipGetLastError();
 }
 
@@ -1730,6 +1791,48 @@ int lgc_apply(const lgc_operator *op, int64_t table_rows, const float *x, int64_
                               y_stride, r, r_stride, a, b, dim, stream);
     }
     const bool tiled = op->n_tile_classes > 0 && dim >= 4;
+    if (tiled && getenv("LGCN_NO_FUSED_APPLY") == nullptr) {
+        // one launch: [chunk workgroups | tile classes], then the fixed-order combine of rows cut into several chunks
+        DimCfg cfg;
+        if (!dim_cfg(dim, &cfg)) return LGC_E_DIM;
+        if (!x || !y || x == y || x_stride < dim || y_stride < dim || (r && r_stride < dim) || op->n_chunks < 0 || op->n_multi < 0 ||
+            (op->n_chunks > 0 && (!op->chunks || !op->rowptr || !op->entries)) || (op->n_multi > 0 && (!op->multi || !op->partials)))
+            return LGC_E_INVAL;
+        FusedArgs f{};
+        f.sp = SpmmArgs{op->rowptr, op->entries, x, y, r, x_stride, y_stride, r_stride, a, b, dim, cfg.lpr, op->row_begin,
+                        op->row_begin, op->short_max, 0};
+        f.sp.wt_store = (table_rows * y_stride * 4 < (int64_t(1) << 32)) ? 1 : 0;
+        f.chunks = op->chunks;
+        f.partials = op->partials;
+        f.n_chunks = op->n_chunks;
+        f.chunk_blocks = op->n_chunks > 0 ? ceil_div(op->n_chunks, kBlock / kWave) : 0;
+        int64_t total = f.chunk_blocks;
+        bool fast = true;
+        for (int c = 0; c < op->n_tile_classes; ++c) {
+            const lgc_tile_class &tc = op->tiles[c];
+            TilePrep tp;
+            const int rc = prepare_tiles(tp, tc.order, tc.meta, tc.slab, tc.n_tiles, tc.width,
+                                         op->tiles_per_wave > 0 ? op->tiles_per_wave : 1, 1, table_rows, x, x_stride, y, y_stride,
+                                         r, r_stride, a, b, dim);
+            if (rc != 0) return rc;
+            if (tc.n_tiles == 0) continue;
+            fast = fast && tp.fast;
+            f.t[f.n_classes] = tp.p;
+            f.width[f.n_classes] = tc.width;
+            f.blocks[f.n_classes] = (int32_t)tp.blocks;
+            total += tp.blocks;
+            ++f.n_classes;
+        }
+        hipStream_t st = as_stream(stream);
+        if (total > 0) {
+            if (fast) hipLaunchKernelGGL((k_apply_fused<true>), dim3((unsigned)total), dim3(kBlock), 0, st, f);
+            else hipLaunchKernelGGL((k_apply_fused<false>), dim3((unsigned)total), dim3(kBlock), 0, st, f);
+        }
+        if (op->n_multi > 0)
+            hipLaunchKernelGGL((k_spmm_combine<4>), dim3(ceil_div(op->n_multi, kBlock / kWave)), dim3(kBlock), 0, st, f.sp, op->multi,
+                               op->n_multi, op->partials);
+        return (int)hipGetLastError();
+    }
     if (!tiled || op->n_chunks > 0) {   // long rows first (they run longest); with tiles the row part gets an empty range
         const int rc = lgc_spmm(op->rowptr, op->entries, op->row_begin, tiled ? op->row_begin : op->row_end, op->short_max,
                                 op->chunks, op->n_chunks, op->multi, op->n_multi, op->partials, table_rows, x, x_stride, y,

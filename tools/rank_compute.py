@@ -21,10 +21,13 @@ for r in ranks:
     pp = PartitionedPropagator(ei, ew, g.n_users, g.n_items, r, world)
     for _ in range(3):
         pp.propagate_sum(x0, alphas)
-    ts = []
+    ts, host = [], []
     for _ in range(10):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         pp.propagate_sum(x0, alphas)
+        t1 = time.perf_counter()                       # everything enqueued: the host's share of a hop
         torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / 3 * 1e6)
-    print(f"world {world} rank {r}: users [{pp.u0},{pp.u1}) local nnz {pp.local_nnz}  compute {statistics.median(ts):.1f} us/hop")
+        host.append((t1 - t0) / 3 * 1e6)
+    print(f"world {world} rank {r}: users [{pp.u0},{pp.u1}) local nnz {pp.local_nnz}  compute {statistics.median(ts):.1f} us/hop"
+          f"  host enqueue {statistics.median(host):.1f} us/hop")
     del pp
