@@ -13,6 +13,7 @@ from .lgconv import LGConv
 from .lightgcn import BPRLoss, LightGCN
 from .propagate import check_index_status, hop, pair_dot, propagate_sum
 from .sampler import TripleSampler
+from . import ingest, serving
 
 __all__ = ["LightGCN", "BPRLoss", "LGConv", "PropGraph", "get_graph", "clear_cache", "build_row_plan",
            "propagate_sum", "hop", "pair_dot", "check_index_status", "TripleSampler", "_native"]

@@ -502,15 +502,19 @@ class PropGraph:
         return self._transpose_op
 
     # -- persistence: a built graph as a flat safetensors file ------------------
-    def save(self, path: str) -> None:
-        """Write the forward operator's CSR, degrees and metadata; nothing executable in the file.
+    def save(self, path: str, extra: Optional[Dict[str, Tensor]] = None, meta: Optional[Dict[str, str]] = None) -> None:
+        """Write the forward operator's CSR, degrees and metadata; nothing executable in the file.  ``extra`` tensors
+        (stored under ``extra.<name>``) and ``meta`` strings ride along -- id maps, purchased-items lists.
         A serving worker can ``PropGraph.load`` it instead of re-reading the CSV, rebuilding the COO
         (torchserve/lightgcn_handler.py:32-38) and sorting it again.  The tile layout is derived data and is
         rebuilt at load time (milliseconds on the device)."""
         from safetensors.torch import save_file
         op = self.forward_op
         tensors = {"rowptr": op.rowptr, "entries": op.entries, "deg": self.deg, "dis": self.dis}
-        meta = {"format": "lgcn-graph-2", "num_nodes": str(self.num_nodes), "num_edges": str(self.num_edges),
+        for k, v in (extra or {}).items():
+            tensors["extra." + k] = v
+        meta = {**{"user." + k: str(v) for k, v in (meta or {}).items()},
+                "format": "lgcn-graph-2", "num_nodes": str(self.num_nodes), "num_edges": str(self.num_edges),
                 "normalize": str(int(self.normalize)), "split": "" if self.split is None else str(self.split)}
         save_file({k: v.detach().cpu().contiguous() for k, v in tensors.items()}, path, metadata=meta)
 
@@ -541,9 +545,10 @@ class PropGraph:
             bad("row pointer is not a non-decreasing 0 .. num_edges sequence, or a column id is outside the graph")
 
     @classmethod
-    def load(cls, path: str, device, short_max: int = SHORT_MAX, chunk_len: int = CHUNK_LEN) -> "PropGraph":
+    def load(cls, path: str, device, short_max: int = SHORT_MAX, chunk_len: int = CHUNK_LEN, with_extra: bool = False):
         """A graph usable for forward propagation (``get_embedding`` / ``recommendK``).  The COO is not stored,
-        so the transposed operator (training) cannot be derived from a loaded graph."""
+        so the transposed operator (training) cannot be derived from a loaded graph.  ``with_extra``: return
+        (graph, extra tensors on the host, user metadata) as written by ``save(extra=..., meta=...)``."""
         from safetensors import safe_open
         device = torch.device(device)
         if device.type != "cuda":
@@ -574,6 +579,9 @@ class PropGraph:
         g._transpose_op = None
         g.split = split
         g._halves = {}
+        if with_extra:
+            return (g, {k[len("extra."):]: v for k, v in t.items() if k.startswith("extra.")},
+                    {k[len("user."):]: v for k, v in meta.items() if k.startswith("user.")})
         return g
 
     def nbytes(self) -> int:
@@ -597,7 +605,13 @@ def _key(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int, norm
             str(edge_index.device), w, int(num_nodes), bool(normalize))
 
 
-def get_graph(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int, normalize: bool = True) -> PropGraph:
+def get_graph(edge_index, edge_weight: Optional[Tensor], num_nodes: int, normalize: bool = True) -> PropGraph:
+    """The cached graph of an ``(edge_index, edge_weight)`` pair; a ``PropGraph`` passed in place of ``edge_index``
+    (a loaded, persisted graph) is used as it is."""
+    if isinstance(edge_index, PropGraph):
+        if edge_index.num_nodes != int(num_nodes):
+            raise ValueError(f"the graph has {edge_index.num_nodes} nodes, the model {num_nodes}")
+        return edge_index
     key = _key(edge_index, edge_weight, num_nodes, normalize)
     g = _CACHE.get(key)
     if g is not None:
