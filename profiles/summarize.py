@@ -36,7 +36,7 @@ def counters(d, sub):
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
 
 
-HOP_KERNELS = ("k_spmm_hop", "k_spmm_combine", "k_lincomb", "k_rows_tile", "k_sweep", "k_combine_rows")
+HOP_KERNELS = ("k_spmm_hop", "k_spmm_combine", "k_lincomb", "k_rows_tile", "k_sweep", "k_combine_rows", "k_apply_fused")
 
 
 def main(d, n_hops=0):
