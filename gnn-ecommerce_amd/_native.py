@@ -54,7 +54,7 @@ class OperatorC(Structure):
     _fields_ = [("rowptr", c_void_p), ("entries", c_void_p), ("chunks", c_void_p), ("multi", c_void_p),
                 ("partials", c_void_p), ("sweep", POINTER(SweepArraysC)), ("tiles", TileClassC * 3),
                 ("row_begin", c_int32), ("row_end", c_int32), ("short_max", c_int32), ("n_chunks", c_int32),
-                ("n_multi", c_int32), ("n_tile_classes", c_int32), ("tiles_per_wave", c_int32), ("parts", c_int32)]
+                ("n_multi", c_int32), ("n_tile_classes", c_int32), ("tiles_per_wave", c_int32), ("reserved", c_int32)]
 
 
 EXCHANGE_FN = CFUNCTYPE(c_int, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p)   # lgc_exchange_fn

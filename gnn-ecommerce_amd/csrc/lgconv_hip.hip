@@ -697,128 +697,9 @@ __device__ __forceinline__ void tiles_body_dpp(const TileArgs &p, const int64_t 
     }
 }
 
-// The same with the row cut into two column halves of one 128-B line each (D = 64): workgroups on XCDs 0-3
-// (blockIdx % 8) compute columns 0..31 of every row, XCDs 4-7 columns 32..63, so an XCD's L2 sees half the bytes of
-// the gathered table (an LRU model of one L2 on the user step: 63 % -> 80 % hits in the locality order).  A lane group
-// is now 8 lanes -- half a DPP row -- so every broadcast is two bank-masked row_newbcast moves (banks 0-1 from the
-// first sub-slot's lane, banks 2-3 from the second's), and a batch is 8 rows: sub-slots 2bt, 2bt+1 of each DPP row.
-// Same tile data, same metadata (a batch's length = max of its two sub-slots' bytes).
-template <int KA, int KB>
-__device__ __forceinline__ int bcast8(int v) {
-    const int a = __builtin_amdgcn_update_dpp(0, v, 0x150 + KA, 0xf, 0x3, false);   // lanes 0-7 of every row <- lane KA
-    return __builtin_amdgcn_update_dpp(a, v, 0x150 + KB, 0xf, 0xC, false);          // lanes 8-15 <- lane KB
-}
-
-template <int W, int L>
-__device__ __forceinline__ void tiles_body_dpp2(const TileArgs &p, const int64_t block) {
-    constexpr int R = 128 * L / W;     // rows per tile
-    constexpr int Wk = W / L;          // entries of a row in one load
-    constexpr int PPR = Wk / 2;        // 16-byte pieces of a row in one load
-    constexpr int B = R / 4;           // sub-slots per DPP row
-    constexpr int NB2 = B / 2;         // batches of 8 rows
-    static_assert(B * PPR == 16 && B % 2 == 0, "two sub-slots per batch and DPP row");
-    const int lane = threadIdx.x & (kWave - 1);
-    const int part = (int)((block & 7) >> 2);
-    const int64_t pblock = (block >> 3) * 4 + (block & 3);
-    const int64_t wave = pblock * (kBlock / kWave) + (threadIdx.x / kWave);
-    int64_t tile = __builtin_amdgcn_readfirstlane((int)(wave * p.tiles_per_wave));
-    if (tile >= p.n_tiles) return;  // wave-uniform
-    const int64_t tile_end = min(tile + (int64_t)p.tiles_per_wave, (int64_t)p.n_tiles);
-    const int l = lane & 15;
-    const unsigned xoff = (unsigned)(part * 32 + (lane & 7) * 4) * 4u;
-    const auto xsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, p.x_bytes, 0x00020000);
-    const auto ysrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.y, 0, p.y_bytes, 0x00020000);
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.r, 0, p.r != nullptr ? p.r_bytes : 0u, 0x00020000);
-    const unsigned xs = (unsigned)p.x_stride * 4u, ys = (unsigned)p.y_stride * 4u, rs = (unsigned)p.r_stride * 4u;
-
-    u4 nxt[L];
-    int32_t nxt_rid = -1;
-#pragma unroll
-    for (int k = 0; k < L; ++k) nxt[k] = p.slab[(tile * L + k) * kWave + lane];
-    if (l < B) nxt_rid = p.order[tile * R + (lane >> 4) * B + l];
-    int32_t nxt_meta = p.meta[tile];
-    for (; tile < tile_end; ++tile) {
-        u4 cur[L];
-#pragma unroll
-        for (int k = 0; k < L; ++k) cur[k] = nxt[k];
-        const int32_t cur_rid = nxt_rid;
-        const int32_t meta = nxt_meta;
-        if (tile + 1 < tile_end) {
-#pragma unroll
-            for (int k = 0; k < L; ++k) nxt[k] = p.slab[((tile + 1) * L + k) * kWave + lane];
-            if (l < B) nxt_rid = p.order[(tile + 1) * R + (lane >> 4) * B + l];
-            nxt_meta = p.meta[tile + 1];
-        }
-#pragma unroll
-        for (int bt = 0; bt < NB2; ++bt) {
-            const int nmax = max((meta >> (16 * bt)) & 0xFF, (meta >> (16 * bt + 8)) & 0xFF);   // scalar
-            const int row24 = bt == 0 ? bcast8<0, 1>(cur_rid) : bcast8<2, 3>(cur_rid);
-            f2 a0 = {0.0f, 0.0f}, a1 = {0.0f, 0.0f};
-            f4 rv = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (p.r != nullptr)
-                rv = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, __umul24(row24, rs) + xoff, 0, 0));
-#pragma unroll
-            for (int k = 0; k < L; ++k) {
-#pragma unroll
-                for (int j0 = 0; j0 < Wk; j0 += 4) {
-                    if (k * Wk + j0 < nmax) {     // wave-uniform
-                        f4 xv[4];
-                        float val[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int colbits = ((j0 + j) & 1) ? (int)cur[k].z : (int)cur[k].x;
-                            const int valbits = ((j0 + j) & 1) ? (int)cur[k].w : (int)cur[k].y;
-                            int col, vb;
-                            // first sub-slot's piece: lane 2 bt PPR + q, second's: lane (2 bt + 1) PPR + q   (q = (j0+j)/2)
-                            switch (2 * bt * PPR + ((j0 + j) >> 1)) {   // compile-time after unrolling
-                                case 0: col = bcast8<0, 0 + PPR>(colbits); vb = bcast8<0, 0 + PPR>(valbits); break;
-                                case 1: col = bcast8<1, 1 + PPR>(colbits); vb = bcast8<1, 1 + PPR>(valbits); break;
-                                case 2: col = bcast8<2, 2 + PPR>(colbits); vb = bcast8<2, 2 + PPR>(valbits); break;
-                                case 3: col = bcast8<3, 3 + PPR>(colbits); vb = bcast8<3, 3 + PPR>(valbits); break;
-                                case 4: col = bcast8<4, (4 + PPR) & 15>(colbits); vb = bcast8<4, (4 + PPR) & 15>(valbits); break;
-                                case 5: col = bcast8<5, (5 + PPR) & 15>(colbits); vb = bcast8<5, (5 + PPR) & 15>(valbits); break;
-                                case 6: col = bcast8<6, (6 + PPR) & 15>(colbits); vb = bcast8<6, (6 + PPR) & 15>(valbits); break;
-                                case 7: col = bcast8<7, (7 + PPR) & 15>(colbits); vb = bcast8<7, (7 + PPR) & 15>(valbits); break;
-                                case 8: col = bcast8<8, (8 + PPR) & 15>(colbits); vb = bcast8<8, (8 + PPR) & 15>(valbits); break;
-                                case 9: col = bcast8<9, (9 + PPR) & 15>(colbits); vb = bcast8<9, (9 + PPR) & 15>(valbits); break;
-                                case 10: col = bcast8<10, (10 + PPR) & 15>(colbits); vb = bcast8<10, (10 + PPR) & 15>(valbits); break;
-                                default: col = bcast8<11, (11 + PPR) & 15>(colbits); vb = bcast8<11, (11 + PPR) & 15>(valbits); break;
-                            }
-                            val[j] = __int_as_float(vb);
-                            xv[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, __umul24(col, xs) + xoff, 0, 0));
-                        }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {   // product rounded, then added (no FMA: -ffp-contract=off)
-                            const f2 v2 = {val[j], val[j]};
-                            const f2 lo = {xv[j].x, xv[j].y}, hi = {xv[j].z, xv[j].w};
-                            a0 = a0 + lo * v2;
-                            a1 = a1 + hi * v2;
-                        }
-                    }
-                }
-            }
-            Acc<4> acc;
-            acc.v[0] = a0.x; acc.v[1] = a0.y; acc.v[2] = a1.x; acc.v[3] = a1.y;
-            if (p.a != 1.0f) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc.v[i] = __fmul_rn(p.a, acc.v[i]);
-            }
-            if (p.r != nullptr) {
-                acc.v[0] = __fadd_rn(acc.v[0], __fmul_rn(p.b, rv.x));
-                acc.v[1] = __fadd_rn(acc.v[1], __fmul_rn(p.b, rv.y));
-                acc.v[2] = __fadd_rn(acc.v[2], __fmul_rn(p.b, rv.z));
-                acc.v[3] = __fadd_rn(acc.v[3], __fmul_rn(p.b, rv.w));
-            }
-            const f4 o = {acc.v[0], acc.v[1], acc.v[2], acc.v[3]};
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o), ysrc, __umul24(row24, ys) + xoff, 0, 16);
-        }
-    }
-}
-
 template <int W, int L>
 __global__ __launch_bounds__(kBlock) void k_rows_tile_dpp(TileArgs p) {
-    if (p.parts == 2) tiles_body_dpp2<W, L>(p, blockIdx.x);
-    else tiles_body_dpp<W, L>(p, blockIdx.x);
+    tiles_body_dpp<W, L>(p, blockIdx.x);
 }
 
 
@@ -940,7 +821,7 @@ struct FusedArgs {
     int32_t width[3], blocks[3];
 };
 
-template <int MODE>   // 0: generic tiles, 1: DPP fast path, 2: DPP fast path on two column halves (segments start at multiples of 8)
+template <bool FAST>
 __global__ __launch_bounds__(kBlock) void k_apply_fused(FusedArgs f) {
     int64_t b = blockIdx.x;
     if (b < f.chunk_blocks) {
@@ -952,11 +833,7 @@ __global__ __launch_bounds__(kBlock) void k_apply_fused(FusedArgs f) {
     for (int c = 0; c < 3; ++c) {
         if (c >= f.n_classes) return;
         if (b < f.blocks[c]) {
-            if constexpr (MODE == 2) {
-                if (f.width[c] == 8) tiles_body_dpp2<8, 1>(f.t[c], b);
-                else if (f.width[c] == 16) tiles_body_dpp2<16, 1>(f.t[c], b);
-                else tiles_body_dpp2<32, 2>(f.t[c], b);
-            } else if constexpr (MODE == 1) {
+            if constexpr (FAST) {
                 if (f.width[c] == 8) tiles_body_dpp<8, 1>(f.t[c], b);
                 else if (f.width[c] == 16) tiles_body_dpp<16, 1>(f.t[c], b);
                 else tiles_body_dpp<32, 2>(f.t[c], b);
@@ -1638,15 +1515,16 @@ int prepare_tiles(TilePrep &out, const int32_t *order, const int32_t *meta, cons
         const uint32_t pad = (uint32_t)(0xFFFFFFull * (uint64_t)(stride * 4));
         return stride * 4 < (1 << 24) && table_bytes(stride) < (int64_t(1) << 32) && (int64_t)pad >= table_bytes(stride);
     };
-    out.fast = meta != nullptr && ((parts == 1 && dim >= 61) || (parts == 2 && dim == 64)) && dim <= 64 && table_rows > 0 &&
-               table_rows < 0xFFFFFF && pad_is_oob(x_stride) && pad_is_oob(y_stride) && (!r || pad_is_oob(r_stride)) &&
+    out.fast = meta != nullptr && parts == 1 && dim >= 61 && dim <= 64 && table_rows > 0 && table_rows < 0xFFFFFF &&
+               pad_is_oob(x_stride) && pad_is_oob(y_stride) && (!r || pad_is_oob(r_stride)) &&
                getenv("LGCN_NO_FAST_TILES") == nullptr;
     if (out.fast) {
         p.x_bytes = (uint32_t)table_bytes(x_stride);
         p.y_bytes = (uint32_t)table_bytes(y_stride);
         p.r_bytes = r ? (uint32_t)table_bytes(r_stride) : 0u;
+    } else if (parts == 2) {
+        out.blocks = ((out.blocks + 3) / 4) * 8;   // XCDs 0-3 and 4-7 each get ceil(blocks / 4) * 4 workgroups
     }
-    if (parts == 2) out.blocks = ((out.blocks + 3) / 4) * 8;   // XCDs 0-3 and 4-7 each get ceil(blocks / 4) * 4 workgroups
     out.p = p;
     return 0;
 }
@@ -1903,13 +1781,6 @@ int lgc_spmm_sweep(const uint32_t *slabs, const int32_t *wave_slab_ptr, const in
     return (int)hipGetLastError();
 }
 
-static int lgc_apply_unfused_impl(const lgc_operator *op, int64_t table_rows, const float *x, int64_t x_stride, float *y,
-                                  int64_t y_stride, const float *r, int64_t r_stride, float a, float b, int32_t dim, void *stream);
-static int lgc_apply_unfused(const lgc_operator *op, int64_t table_rows, const float *x, int64_t x_stride, float *y,
-                             int64_t y_stride, const float *r, int64_t r_stride, float a, float b, int32_t dim, void *stream) {
-    return lgc_apply_unfused_impl(op, table_rows, x, x_stride, y, y_stride, r, r_stride, a, b, dim, stream);
-}
-
 int lgc_apply(const lgc_operator *op, int64_t table_rows, const float *x, int64_t x_stride, float *y, int64_t y_stride,
               const float *r, int64_t r_stride, float a, float b, int32_t dim, void *stream) {
     if (!op || op->n_tile_classes < 0 || op->n_tile_classes > 3) return LGC_E_INVAL;
@@ -1934,18 +1805,15 @@ int lgc_apply(const lgc_operator *op, int64_t table_rows, const float *x, int64_
         f.chunks = op->chunks;
         f.partials = op->partials;
         f.n_chunks = op->n_chunks;
-        // two column halves on the two XCD groups: only the DPP fast path at D = 64 has it inside a fused launch
-        const int parts = (op->parts == 2 && dim == 64) ? 2 : 1;
         f.chunk_blocks = op->n_chunks > 0 ? ceil_div(op->n_chunks, kBlock / kWave) : 0;
-        if (parts == 2) f.chunk_blocks = (f.chunk_blocks + 7) / 8 * 8;       // every segment starts at a multiple of 8
         int64_t total = f.chunk_blocks;
         bool fast = true;
         for (int c = 0; c < op->n_tile_classes; ++c) {
             const lgc_tile_class &tc = op->tiles[c];
             TilePrep tp;
             const int rc = prepare_tiles(tp, tc.order, tc.meta, tc.slab, tc.n_tiles, tc.width,
-                                         op->tiles_per_wave > 0 ? op->tiles_per_wave : 1, parts, table_rows, x, x_stride, y,
-                                         y_stride, r, r_stride, a, b, dim);
+                                         op->tiles_per_wave > 0 ? op->tiles_per_wave : 1, 1, table_rows, x, x_stride, y, y_stride,
+                                         r, r_stride, a, b, dim);
             if (rc != 0) return rc;
             if (tc.n_tiles == 0) continue;
             fast = fast && tp.fast;
@@ -1956,23 +1824,15 @@ int lgc_apply(const lgc_operator *op, int64_t table_rows, const float *x, int64_
             ++f.n_classes;
         }
         hipStream_t st = as_stream(stream);
-        if (parts == 2 && !fast) return lgc_apply_unfused(op, table_rows, x, x_stride, y, y_stride, r, r_stride, a, b, dim, stream);
         if (total > 0) {
-            if (fast && parts == 2) hipLaunchKernelGGL((k_apply_fused<2>), dim3((unsigned)total), dim3(kBlock), 0, st, f);
-            else if (fast) hipLaunchKernelGGL((k_apply_fused<1>), dim3((unsigned)total), dim3(kBlock), 0, st, f);
-            else hipLaunchKernelGGL((k_apply_fused<0>), dim3((unsigned)total), dim3(kBlock), 0, st, f);
+            if (fast) hipLaunchKernelGGL((k_apply_fused<true>), dim3((unsigned)total), dim3(kBlock), 0, st, f);
+            else hipLaunchKernelGGL((k_apply_fused<false>), dim3((unsigned)total), dim3(kBlock), 0, st, f);
         }
         if (op->n_multi > 0)
             hipLaunchKernelGGL((k_spmm_combine<4>), dim3(ceil_div(op->n_multi, kBlock / kWave)), dim3(kBlock), 0, st, f.sp, op->multi,
                                op->n_multi, op->partials);
         return (int)hipGetLastError();
     }
-    return lgc_apply_unfused(op, table_rows, x, x_stride, y, y_stride, r, r_stride, a, b, dim, stream);
-}
-
-static int lgc_apply_unfused_impl(const lgc_operator *op, int64_t table_rows, const float *x, int64_t x_stride, float *y,
-                                  int64_t y_stride, const float *r, int64_t r_stride, float a, float b, int32_t dim, void *stream) {
-    const bool tiled = op->n_tile_classes > 0 && dim >= 4;
     if (!tiled || op->n_chunks > 0) {   // long rows first (they run longest); with tiles the row part gets an empty range
         const int rc = lgc_spmm(op->rowptr, op->entries, op->row_begin, tiled ? op->row_begin : op->row_end, op->short_max,
                                 op->chunks, op->n_chunks, op->multi, op->n_multi, op->partials, table_rows, x, x_stride, y,

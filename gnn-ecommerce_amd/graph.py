@@ -39,9 +39,6 @@ TILES_PER_WAVE = int(os.environ.get("LGCN_TILES_PER_WAVE", "1"))      # 1 ~ 2 > 
 # share a rarely used table row run close together in time and that row crosses the fabric about once
 # (an LRU model of one 4 MiB L2 gives 47 % -> 63 % hits on the user step); "natural": row order.
 TILE_ORDER = os.environ.get("LGCN_TILE_ORDER", "cold")
-# 2: at D = 64 the tiled rows are computed as two column halves, one per XCD group, so that an XCD's L2 sees half the
-# bytes of the gathered table (see tiles_body_dpp2 in csrc/lgconv_hip.hip); 1: whole rows everywhere.
-TILE_PARTS = int(os.environ.get("LGCN_TILE_PARTS", "2"))
 # Band sweep for the long rows of a bipartite half whose gathered table is far larger than the caches (the item
 # step): "auto" = when the half has at least SWEEP_MIN_ENTRIES entries, "1" = whenever the table qualifies, "0" = never.
 USE_SWEEP = os.environ.get("LGCN_SWEEP", "auto")
@@ -357,7 +354,6 @@ class Operator:
         c.partials = _native.ptr(self.partials(dim))
         c.row_begin, c.row_end, c.short_max, c.n_chunks, c.n_multi = p.row_begin, p.row_end, p.short_max, p.n_chunks, p.n_multi
         c.tiles_per_wave = TILES_PER_WAVE
-        c.parts = TILE_PARTS
         keep = [c]
         if self.tiled and dim >= 4:
             for i, tc in enumerate(self.tiles):

@@ -254,8 +254,7 @@ typedef struct lgc_operator {
     float   *partials;           /* scratch of the chunk plan, [n_slots, dim] or NULL */
     const lgc_sweep_arrays *sweep;   /* HOST pointer or NULL */
     lgc_tile_class tiles[3];
-    int32_t row_begin, row_end, short_max, n_chunks, n_multi, n_tile_classes, tiles_per_wave;
-    int32_t parts;               /* 1, or 2: tiled rows of a 64-wide table as two column halves on the two XCD groups */
+    int32_t row_begin, row_end, short_max, n_chunks, n_multi, n_tile_classes, tiles_per_wave, reserved;
 } lgc_operator;
 
 int lgc_apply(const lgc_operator *op, int64_t table_rows, const float *x, int64_t x_stride, float *y, int64_t y_stride,
