@@ -98,6 +98,16 @@ class LightGCN(torch.nn.Module):
             self._served = (key, graph, self.get_embedding(edge_index, edge_weight))
         return self._served[2]
 
+    def invalidate(self) -> None:
+        """Forget every derived table: the cached graphs of this process and the propagated table ``recommendK``
+        reuses.  The caches key on tensor identity + version counter, which in-place torch ops bump; call this after
+        writes that do not (``weight.data.copy_``, a DLPack/numpy alias, a foreign kernel).  The reference re-derives
+        everything on every call."""
+        from .graph import clear_cache
+        clear_cache()
+        self._served = None
+        self._alpha_host = None
+
     def forward(self, edge_index, edge_label_index: Optional[Tensor] = None,
                 edge_weight: Optional[Tensor] = None) -> Tensor:
         """Scores of the node pairs in ``edge_label_index`` (default: the graph's own edges)."""

@@ -186,6 +186,31 @@ def _status(device: torch.device) -> Tensor:
     return t
 
 
+_status_snapshots = {}
+
+
+def _snapshot_status(device: torch.device) -> None:
+    """Enqueue an asynchronous copy of the status word to pinned host memory (after a scoring launch); the next
+    scoring call looks at it without waiting."""
+    snap = _status_snapshots.get(device)
+    if snap is None:
+        snap = (torch.zeros(4, dtype=torch.int32).pin_memory(), torch.cuda.Event())
+        _status_snapshots[device] = snap
+    snap[0].copy_(_status(device), non_blocking=True)
+    snap[1].record(torch.cuda.current_stream(device))
+
+
+def raise_pending_index_error(device: torch.device) -> None:
+    """Non-blocking: if an EARLIER scoring launch on this device has finished and flagged an out-of-range label
+    index, raise IndexError now (the reference's gather raises at the faulty call; here the kernels never fault and
+    the error surfaces at the next call, or at ``check_index_status()``)."""
+    snap = _status_snapshots.get(device)
+    if snap is not None and snap[1].query() and int(snap[0][0]) & _native.ST_INDEX_OOB:
+        snap[0].zero_()
+        _status(device).zero_()
+        raise IndexError("edge_label_index of an earlier call contained node ids outside [0, num_nodes)")
+
+
 def check_index_status(device: Optional[torch.device] = None) -> None:
     """Synchronising check: raise IndexError if any pair-scoring launch since the last check saw an
     out-of-range label index (the kernels skip such pairs and score them NaN instead of faulting)."""
@@ -194,6 +219,10 @@ def check_index_status(device: Optional[torch.device] = None) -> None:
             continue
         if int(t[0].item()) & _native.ST_INDEX_OOB:
             t.zero_()
+            snap = _status_snapshots.get(dev)
+            if snap is not None:
+                snap[1].synchronize()
+                snap[0].zero_()
             raise IndexError("edge_label_index contains node ids outside [0, num_nodes)")
 
 
@@ -209,6 +238,7 @@ class _PairDot(torch.autograd.Function):
                                     _native.ptr(idx0), _native.ptr(idx1), idx0.numel(), _native.ptr(scores),
                                     _native.ptr(_status(emb.device)), _native.stream_of(emb.device))
         _native.check(code, "lgc_pair_dot")
+        _snapshot_status(emb.device)
         ctx.save_for_backward(emb_c, idx0, idx1)
         return scores
 
@@ -313,6 +343,7 @@ class _ScoresFromTable(torch.autograd.Function):
                                     _native.ptr(idx1), idx0.numel(), _native.ptr(scores), _native.ptr(_status(emb.device)),
                                     _native.stream_of(emb.device))
         _native.check(code, "lgc_pair_dot")
+        _snapshot_status(emb.device)
         n = emb.size(0)
         ok = (idx0 >= 0) & (idx0 < n) & (idx1 >= 0) & (idx1 < n)       # invalid pairs score NaN and carry no gradient
         i0, i1 = idx0.clamp(0, n - 1), idx1.clamp(0, n - 1)
@@ -337,6 +368,7 @@ def scores_from_table(w: Tensor, graph: PropGraph, alphas: Sequence[float], edge
     _native.require_device(edge_label_index, "edge_label_index")
     if edge_label_index.dtype != torch.int64 or edge_label_index.dim() != 2 or edge_label_index.size(0) != 2:
         raise TypeError("edge_label_index must be an int64 tensor of shape [2, M]")
+    raise_pending_index_error(w.device)
     alphas = tuple(float(a) for a in alphas)
     sparse_ok = (SPARSE_BACKWARD and torch.is_grad_enabled() and w.requires_grad and graph.split is not None
                  and USE_BIPARTITE and len(alphas) - 1 <= _native.MAX_TERMS - 1

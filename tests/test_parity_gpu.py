@@ -778,3 +778,30 @@ def test_seeded_backward_equals_the_dense_backward_and_the_oracle(device, dim, l
     assert torch.isfinite(model.embedding.weight.grad).all()
     with pytest.raises(IndexError):
         lg.check_index_status()
+
+
+def test_invalidate_after_an_untracked_write_and_late_index_errors(device):
+    """ADVICE r1: (1) writes that bypass the version counter are invisible to the caches until invalidate();
+    (2) an out-of-range label index surfaces as IndexError at the NEXT scoring call without any added sync."""
+    g, ei, ew = small_graph(4, 300, 60, 2500)
+    ei, ew = ei.to(device), ew.to(device)
+    model = lg.LightGCN(g.num_nodes, 64, 2).to(device).eval()
+    users, seen = [1, 2, 3], torch.zeros(3, g.n_items)
+    with torch.no_grad():
+        a = model.recommendK(ei, ew, g.n_users, g.n_items, seen, users, 5)
+        model.embedding.weight.data.copy_(torch.randn_like(model.embedding.weight))    # no version bump on .data
+        stale = model.recommendK(ei, ew, g.n_users, g.n_items, seen, users, 5)
+        assert stale.equals(a)                                                          # documented: identity + version
+        model.invalidate()
+        fresh = model.recommendK(ei, ew, g.n_users, g.n_items, seen, users, 5)
+        emb = model.get_embedding(ei, ew).cpu()
+    want = oracle.recommend_topk(emb, g.n_users, g.n_items, seen, users, 5)
+    assert np.array_equal(np.array(fresh["top_rlvnt_itm"].tolist()), want.numpy()) and not fresh.equals(a)
+    bad = torch.tensor([[0, 1], [g.num_nodes + 1, 2]], device=device)
+    out = model(ei, bad, ew)
+    assert torch.isnan(out[0]) and not torch.isnan(out[1])
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError):
+        model(ei, torch.tensor([[0], [1]], device=device), ew)                           # the NEXT call reports it
+    model(ei, torch.tensor([[0], [1]], device=device), ew)                               # and the flag is cleared
+    lg.check_index_status()
