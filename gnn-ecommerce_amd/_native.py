@@ -26,7 +26,7 @@ ST_SAMPLER_EXHAUSTED = 2
 class SweepCfg(Structure):
     """lgc_sweep_cfg"""
     _fields_ = [("n_bands", c_int32), ("waves_per_band_round", c_int32), ("row_cap", c_int32), ("piece_cap", c_int32),
-                ("lookahead", c_int32)]
+                ("lookahead", c_int32), ("sequential", c_int32)]
 
 
 class SweepDims(Structure):
@@ -90,7 +90,8 @@ SIGNATURES = {
     "lgc_seed_push": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p, c_int64, c_int32,
                               c_void_p]),
     "lgc_lincomb": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p]),
-    "lgc_mask_topk": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "lgc_mask_topk": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
+                              c_void_p, c_void_p, c_void_p]),
     "lgc_sample_triples": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_uint64,
                                    c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lgc_pair_dot": (c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_int64, c_void_p,

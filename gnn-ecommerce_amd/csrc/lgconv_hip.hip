@@ -1078,16 +1078,35 @@ __device__ __forceinline__ uint32_t order_key(float v) {
 }
 
 __global__ __launch_bounds__(kTopkBlock) void k_mask_topk(const float *__restrict__ scores, int64_t score_stride,
-                                                         const float *__restrict__ seen, int64_t seen_stride, int32_t n_cols,
+                                                         const float *__restrict__ seen, int64_t seen_stride,
+                                                         const int64_t *__restrict__ list_ptr,
+                                                         const int64_t *__restrict__ list_items,
+                                                         const int64_t *__restrict__ list_rows, int32_t n_cols,
                                                          int32_t k, int64_t *__restrict__ out_index,
                                                          float *__restrict__ out_value) {
+    extern __shared__ uint32_t seen_bits[];     // list form of the mask: one bit per column, built here
     __shared__ uint32_t hist[2048];
     __shared__ unsigned long long cand[kTopkMax];
     __shared__ uint32_t sh_bin, sh_need, sh_count, sh_wave[kTopkBlock / kWave];
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
     const float *srow = scores + (int64_t)blockIdx.x * score_stride;
     const float *mrow = seen ? seen + (int64_t)blockIdx.x * seen_stride : nullptr;
-    auto masked = [&](float s, float m) { return mrow ? __fmul_rn(s, __fsub_rn(1.0f, m)) : s; };
+    const bool listed = list_ptr != nullptr;
+    if (listed) {   // seen items of this row's user as a bitmask in LDS: the dense [rows, n_cols] mask never exists
+        for (int b = tid; b < (n_cols + 31) / 32; b += kTopkBlock) seen_bits[b] = 0u;
+        __syncthreads();
+        const int64_t u = list_rows ? list_rows[blockIdx.x] : (int64_t)blockIdx.x;
+        for (int64_t e = list_ptr[u] + tid; e < list_ptr[u + 1]; e += kTopkBlock) {
+            const int64_t it = list_items[e];
+            if (it >= 0 && it < n_cols) atomicOr(&seen_bits[it >> 5], 1u << (it & 31));
+        }
+        __syncthreads();
+    }
+    // score * (1 - seen) in upstream's arithmetic; the list form has seen = 1 for listed columns, 0 elsewhere
+    auto masked_at = [&](float s, float m, int i) {
+        if (listed) return (seen_bits[i >> 5] >> (i & 31)) & 1u ? __fmul_rn(s, 0.0f) : s;
+        return mrow ? __fmul_rn(s, __fsub_rn(1.0f, m)) : s;
+    };
     uint32_t prefix = 0, mask = 0, need = (uint32_t)k, eq_total = 0;
     const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
     for (int pass = 0; pass < 3; ++pass) {
@@ -1105,7 +1124,7 @@ __global__ __launch_bounds__(kTopkBlock) void k_mask_topk(const float *__restric
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int i = base + j * kTopkBlock + tid;
-                const uint32_t key = order_key(masked(sv[j], mv[j]));
+                const uint32_t key = i < n_cols ? order_key(masked_at(sv[j], mv[j], i)) : 0u;
                 if (i < n_cols && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & (nb - 1)], 1u);
             }
         }
@@ -1144,7 +1163,7 @@ __global__ __launch_bounds__(kTopkBlock) void k_mask_topk(const float *__restric
     uint32_t eq_taken = 0;                                  // block-uniform, only used when ties_cut
     for (int base = 0; base < n_cols; base += kTopkBlock) {
         const int i = base + tid;
-        const uint32_t key = i < n_cols ? order_key(masked(srow[i], mrow ? mrow[i] : 0.0f)) : 0u;
+        const uint32_t key = i < n_cols ? order_key(masked_at(srow[i], mrow ? mrow[i] : 0.0f, i)) : 0u;
         const bool gt = i < n_cols && key > T, eq = i < n_cols && key == T;
         if (gt || (eq && !ties_cut)) {
             const uint32_t pos = atomicAdd(&sh_count, 1u);
@@ -1180,7 +1199,7 @@ __global__ __launch_bounds__(kTopkBlock) void k_mask_topk(const float *__restric
         const unsigned long long c = cand[tid];
         const uint32_t idx = 0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFull);
         out_index[(int64_t)blockIdx.x * k + tid] = (int64_t)idx;
-        if (out_value) out_value[(int64_t)blockIdx.x * k + tid] = masked(srow[idx], mrow ? mrow[idx] : 0.0f);
+        if (out_value) out_value[(int64_t)blockIdx.x * k + tid] = masked_at(srow[idx], mrow ? mrow[idx] : 0.0f, (int)idx);
     }
 }
 
@@ -1381,7 +1400,9 @@ int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry 
             const int64_t lap = (int64_t)(k / (size_t)U), pos = (int64_t)(k % (size_t)U);
             const int64_t u = (lap & 1) ? (U - 1 - pos) : pos;
             const int64_t r = u / WPBR, j = u % WPBR;
-            const int64_t w = ((r * (WPBR / 4) + j / 4) * NB + b) * 4 + (j % 4);   // block = (r, j / 4, band), band = block % NB
+            // bands side by side: block = (r, j / 4, band), band = block % NB (one band per XCD, all bands at once);
+            // bands one after the other: all waves of band b precede those of band b + 1 (dispatch order = time order)
+            const int64_t w = cfg.sequential ? (int64_t)b * U + u : ((r * (WPBR / 4) + j / 4) * NB + b) * 4 + (j % 4);
             wave_pieces[(size_t)w].push_back(v[k]);
         }
     }
@@ -1915,15 +1936,27 @@ int lgc_pair_dot_backward(const float *grad_scores, const float *emb, int64_t st
     return (int)hipGetLastError();
 }
 
-int lgc_mask_topk(const float *scores, int64_t score_stride, const float *seen, int64_t seen_stride, int64_t n_rows,
-                  int32_t n_cols, int32_t k, int64_t *out_index, float *out_value, void *stream_) {
+int lgc_mask_topk(const float *scores, int64_t score_stride, const float *seen, int64_t seen_stride, const int64_t *list_ptr,
+                  const int64_t *list_items, const int64_t *list_rows, int64_t n_rows, int32_t n_cols, int32_t k,
+                  int64_t *out_index, float *out_value, void *stream_) {
     if (!scores || !out_index || n_rows < 0 || n_cols < 1 || k < 1 || k > n_cols || score_stride < n_cols ||
-        (seen && seen_stride < n_cols) || n_rows >= INT32_MAX)
+        (seen && seen_stride < n_cols) || n_rows >= INT32_MAX || (seen && list_ptr) || (list_ptr && !list_items))
         return LGC_E_INVAL;
     if (k > kTopkMax) return LGC_E_RANGE;
+    const size_t lds = list_ptr ? (size_t)((n_cols + 31) / 32) * 4 : 0;
+    if (lds > 128 * 1024) return LGC_E_RANGE;             // the bitmask form holds up to 1,048,576 columns
     if (n_rows == 0) return 0;
-    hipLaunchKernelGGL(k_mask_topk, dim3((unsigned)n_rows), dim3(kTopkBlock), 0, as_stream(stream_), scores, score_stride, seen,
-                       seen_stride, n_cols, k, out_index, out_value);
+    if (lds > 48 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mask_topk),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL(k_mask_topk, dim3((unsigned)n_rows), dim3(kTopkBlock), lds, as_stream(stream_), scores, score_stride, seen,
+                       seen_stride, list_ptr, list_items, list_rows, n_cols, k, out_index, out_value);
     return (int)hipGetLastError();
 }
 

@@ -45,10 +45,11 @@ USE_SWEEP = os.environ.get("LGCN_SWEEP", "auto")
 SWEEP_MIN_ENTRIES = int(os.environ.get("LGCN_SWEEP_MIN_ENTRIES", "2000000"))
 # 8 wavefronts per CU with 78 accumulators each beat 16 x 39 (44 % vs 20 % L2 hits on the item step: fewer, longer
 # lists keep the wavefronts of a band closer together); 160 KiB of LDS per CU either way.
-SWEEP_CFG = dict(n_bands=8, waves_per_band_round=int(os.environ.get("LGCN_SWEEP_WAVES", "256")),
+SWEEP_CFG = dict(n_bands=int(os.environ.get("LGCN_SWEEP_BANDS", "8")), waves_per_band_round=int(os.environ.get("LGCN_SWEEP_WAVES", "256")),
                  row_cap=int(os.environ.get("LGCN_SWEEP_ROW_CAP", "78")),
                  piece_cap=int(os.environ.get("LGCN_SWEEP_PIECE_CAP", "64")),
-                 lookahead=int(os.environ.get("LGCN_SWEEP_LOOKAHEAD", "64")))
+                 lookahead=int(os.environ.get("LGCN_SWEEP_LOOKAHEAD", "64")),
+                 sequential=int(os.environ.get("LGCN_SWEEP_SEQUENTIAL", "0")))
 
 
 @dataclass

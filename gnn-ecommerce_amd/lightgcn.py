@@ -21,7 +21,7 @@ from torch.nn.modules.loss import _Loss
 from . import _native
 from .graph import get_graph
 from .lgconv import LGConv
-from .propagate import TOPK_MAX, mask_topk, pair_dot, propagate_sum, scores_from_table
+from .propagate import TOPK_MAX, SeenLists, mask_topk, pair_dot, propagate_sum, scores_from_table
 
 __all__ = ["LightGCN", "BPRLoss", "LGConv"]
 
@@ -152,7 +152,13 @@ class LightGCN(torch.nn.Module):
         # products as ``torch.mul(pred.cpu(), 1 - interactions_t)``; the mask may already live on the device.
         sel = torch.as_tensor(user_id_list, device=embeds.device) if not torch.is_tensor(user_id_list) \
             else user_id_list.to(embeds.device)
-        pred = users.index_select(0, sel.reshape(-1).long()) @ items.t()
+        sel = sel.reshape(-1).long()
+        pred = users.index_select(0, sel) @ items.t()
+        if isinstance(interactions_t, SeenLists):                    # purchase lists on the device: no dense mask at all
+            if k > TOPK_MAX:
+                raise ValueError(f"the list form of the mask supports k <= {TOPK_MAX}")
+            top_index = mask_topk(pred, interactions_t.for_users(sel), k).cpu()
+            return pd.DataFrame({'user_ID': list(user_id_list), 'top_rlvnt_itm': top_index.numpy().tolist()})
         seen = interactions_t.to(device=embeds.device, dtype=pred.dtype, non_blocking=True)
         if k <= TOPK_MAX:
             top_index = mask_topk(pred, seen.expand_as(pred).contiguous(), k).cpu()       # one launch: lgc_mask_topk

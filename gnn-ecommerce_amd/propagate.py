@@ -395,9 +395,23 @@ def pair_dot(emb: Tensor, edge_label_index: Tensor) -> Tensor:
 TOPK_MAX = 256
 
 
-def mask_topk(scores: Tensor, seen: Optional[Tensor], k: int) -> Tensor:
+class SeenLists:
+    """The purchase matrix as a device CSR (``ptr`` int64 [n_users + 1], ``items`` int64) plus the users of a
+    request: the list form of ``recommendK``'s ``interactions_t`` (seen = 1 for listed items)."""
+
+    def __init__(self, ptr: Tensor, items: Tensor, users: Optional[Tensor] = None):
+        self.ptr, self.items, self.users = ptr, items, users
+
+    def for_users(self, users: Tensor) -> "SeenLists":
+        return SeenLists(self.ptr, self.items, users)
+
+
+def mask_topk(scores: Tensor, seen, k: int) -> Tensor:
     """Indices [rows, k] (int64, on the device) of the k largest ``scores * (1 - seen)`` per row, ties by lower index
-    (src/lightgcn.py:175-177).  ``seen`` may be None.  k <= 256."""
+    (src/lightgcn.py:175-177).  ``seen``: a dense fp32 tensor, a ``SeenLists``, or None.  k <= 256."""
+    lists = seen if isinstance(seen, SeenLists) else None
+    if lists is not None:
+        seen = None
     _native.require_device(scores, "scores")
     if scores.dtype != torch.float32 or scores.dim() != 2 or scores.stride(1) != 1:
         raise TypeError("scores must be a 2-D fp32 tensor with unit inner stride")
@@ -412,6 +426,8 @@ def mask_topk(scores: Tensor, seen: Optional[Tensor], k: int) -> Tensor:
     lib = _native.load()
     with torch.cuda.device(scores.device):
         code = lib.lgc_mask_topk(_native.ptr(scores), scores.stride(0), _native.ptr(seen), 0 if seen is None else seen.stride(0),
-                                 rows, cols, k, _native.ptr(out), None, _native.stream_of(scores.device))
+                                 _native.ptr(lists.ptr) if lists else None, _native.ptr(lists.items) if lists else None,
+                                 _native.ptr(lists.users) if lists else None, rows, cols, k, _native.ptr(out), None,
+                                 _native.stream_of(scores.device))
     _native.check(code, "lgc_mask_topk")
     return out

@@ -6,8 +6,9 @@ handler -- ``context.manifest['model']['serializedFile']``, ``context.system_pro
 returns what upstream returns, ``[{'items': [[k item indices], ...]}]``.  What differs is where the time goes:
   * ``initialize`` loads the persisted graph (``ingest.save_serving_graph``) instead of re-reading the CSV and
     rebuilding the COO (lightgcn_handler.py:32-38), and keeps the purchased-items lists on the device as a CSR;
-  * ``inference`` builds the request's seen rows on the device and calls ``LightGCN.recommendK`` with the graph object:
-    the K-layer propagate is reused across requests, scores / mask / top-k stay on the device (lgc_mask_topk).
+  * ``inference`` calls ``LightGCN.recommendK`` with the graph object and the purchase lists (``SeenLists``): the K-layer
+    propagate is reused across requests, scores / mask / top-k stay on the device (lgc_mask_topk builds the request's
+    mask rows as bitmasks in LDS; the dense ``[n_sel, n_items]`` mask upstream materialises never exists).
 """
 from __future__ import annotations
 
@@ -19,6 +20,7 @@ import torch
 from . import _native
 from .graph import PropGraph
 from .lightgcn import LightGCN
+from .propagate import SeenLists
 
 GRAPH_FILE = "graph.safetensors"
 
@@ -49,6 +51,7 @@ class RecommendHandler:
         self.graph, extra, meta = PropGraph.load(graph_path, self.device, with_extra=True)
         self.n_users, self.n_items = int(meta["n_users"]), int(meta["n_items"])
         self.seen_ptr, self.seen_items = extra["seen_ptr"].to(self.device), extra["seen_items"].to(self.device)
+        self.seen = SeenLists(self.seen_ptr, self.seen_items)
         state = load_checkpoint(model_pt_path)
         hp = state["hyperparams"]
         self.model = LightGCN(self.n_users + self.n_items, hp["latent_dim"], hp["n_layers"])
@@ -76,9 +79,8 @@ class RecommendHandler:
 
     def inference(self, data, *args, **kwargs):
         with torch.no_grad():
-            users = torch.as_tensor(data, device=self.device).reshape(-1).long()
-            frame = self.model.recommendK(self.graph, None, self.n_users, self.n_items, self.seen_rows(users),
-                                          list(data), self.k)
+            # the purchase lists stay a CSR on the device; lgc_mask_topk turns the request's rows into LDS bitmasks
+            frame = self.model.recommendK(self.graph, None, self.n_users, self.n_items, self.seen, list(data), self.k)
             return {"items": list(frame["top_rlvnt_itm"])}
 
     def postprocess(self, data) -> List[dict]:

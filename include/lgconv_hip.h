@@ -189,6 +189,10 @@ typedef struct lgc_sweep_cfg {
     int32_t piece_cap;             /* 64: longest run of one row's entries inside one wavefront's list; raised in
                                       steps of 16 (up to 4x) while that saves a whole round                */
     int32_t lookahead;             /* 64: how far the step builder looks for an entry of another piece  */
+    int32_t sequential;            /* 0: band b runs on XCD b, all bands at once (several rounds when the pieces of a band
+                                      exceed one XCD's LDS); 1: the bands run one after the other on the whole chip
+                                      (waves_per_band_round = all wavefronts of the chip, normally one round): a band then
+                                      fits the Infinity Cache, so re-fetches by other XCDs are on-die                    */
 } lgc_sweep_cfg;
 
 typedef struct lgc_sweep_dims {
@@ -304,10 +308,15 @@ int lgc_pair_dot_backward(const float *grad_scores, const float *emb, int64_t st
 /* Serving tail of LightGCN.recommendK (src/lightgcn.py:175-177; called per request from
  * torchserve/lightgcn_handler.py:91): masked = scores * (1 - seen), then per row the k largest by
  * (value descending, index ascending), entirely on the device -- upstream copies the [rows, n_cols] score matrix
- * to the host first.  seen may be NULL (no mask).  k <= 256 (LGC_E_RANGE beyond).
- *   scores fp32 [n_rows, n_cols] (row stride in floats), seen fp32 same shape,
- *   out_index int64 [n_rows, k], out_value fp32 [n_rows, k] or NULL. */
-int lgc_mask_topk(const float *scores, int64_t score_stride, const float *seen, int64_t seen_stride, int64_t n_rows,
+ * to the host first.  k <= 256 (LGC_E_RANGE beyond).  The mask comes in one of two forms (or neither: NULL, NULL):
+ *   dense   seen fp32 [n_rows, n_cols], any values -- what upstream's handler builds per request
+ *           (index_select on the sparse purchase matrix + to_dense, lightgcn_handler.py:88);
+ *   lists   list_ptr int64 [n_users + 1], list_items int64 (a CSR of the purchase matrix, seen = 1 for listed
+ *           columns), list_rows int64 [n_rows] = the user of each score row (NULL: row r is user r): the kernel
+ *           builds a bit per column in LDS, the dense mask never exists (n_cols <= 1,048,576).
+ *   scores fp32 [n_rows, n_cols] (row stride in floats), out_index int64 [n_rows, k], out_value fp32 [n_rows, k] or NULL. */
+int lgc_mask_topk(const float *scores, int64_t score_stride, const float *seen, int64_t seen_stride,
+                  const int64_t *list_ptr, const int64_t *list_items, const int64_t *list_rows, int64_t n_rows,
                   int32_t n_cols, int32_t k, int64_t *out_index, float *out_value, void *stream);
 
 /* ---------------------------------------------------------------------------------------

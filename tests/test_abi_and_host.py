@@ -377,7 +377,8 @@ def _decode_sweep(dims, arr, row_cap):
 
 @pytest.mark.parametrize("cfg", [dict(n_bands=8, waves_per_band_round=16, row_cap=39, piece_cap=64, lookahead=32),
                                  dict(n_bands=3, waves_per_band_round=4, row_cap=7, piece_cap=5, lookahead=4),
-                                 dict(n_bands=1, waves_per_band_round=8, row_cap=200, piece_cap=1000, lookahead=64)])
+                                 dict(n_bands=1, waves_per_band_round=8, row_cap=200, piece_cap=1000, lookahead=64),
+                                 dict(n_bands=4, waves_per_band_round=64, row_cap=78, piece_cap=64, lookahead=64, sequential=1)])
 def test_sweep_plan_holds_every_entry_once_in_conflict_free_steps(cfg):
     from gnn_ecommerce_amd.graph import sweep_plan_host
     g = synth.make_bipartite(3000, 120, 26000, seed=4)
@@ -419,7 +420,8 @@ def test_sweep_plan_argument_errors():
     code = ct.c_int(0)
 
     def create(lo=0, hi=8, **kw):
-        cfg = _native.SweepCfg(**{**dict(n_bands=8, waves_per_band_round=16, row_cap=39, piece_cap=64, lookahead=32), **kw})
+        cfg = _native.SweepCfg(**{**dict(n_bands=8, waves_per_band_round=16, row_cap=39, piece_cap=64, lookahead=32,
+                                         sequential=0), **kw})
         h = lib.lgc_sweep_plan_create(rowptr.data_ptr(), entries.data_ptr(), 0, 2, lo, hi, ct.byref(cfg), ct.byref(code))
         if h:
             lib.lgc_sweep_plan_free(h)

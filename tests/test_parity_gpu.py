@@ -680,6 +680,17 @@ def test_mask_topk_matches_torch_and_breaks_ties_by_index(device, rows, cols, k)
     assert got.dtype == torch.int64 and got.shape == (rows, k)
     assert torch.equal(torch.gather(masked, 1, got), want.values)                 # the same values in the same order
     assert all(len(set(r)) == k for r in got.tolist())
+    # the list form of the same mask (CSR of seen columns per user, rows -> users through an index)
+    from gnn_ecommerce_amd.propagate import SeenLists
+    n_users = rows + 3
+    users = torch.randperm(n_users, generator=gen)[:rows]
+    full = torch.zeros(n_users, cols)
+    full[users] = seen
+    ptr = torch.zeros(n_users + 1, dtype=torch.int64)
+    ptr[1:] = torch.cumsum(full.sum(dim=1).long(), 0)
+    items_l = torch.nonzero(full)[:, 1]
+    lists = SeenLists(ptr.to(device), items_l.to(device), users.to(device))
+    assert torch.equal(mask_topk(scores.to(device), lists, k).cpu(), got)
     # no mask; a strided view of the scores
     wide = torch.randn(rows, cols + 5, generator=gen).to(device)
     got2 = mask_topk(wide[:, :cols], None, k).cpu()

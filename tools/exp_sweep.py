@@ -44,13 +44,13 @@ def main():
     chunked.apply(x, ref, a=0.5, r=r, b=0.25)
     print(f"chunked item half: {timed(lambda: chunked.apply(x, ref, a=0.5, r=r, b=0.25)):.1f} us", flush=True)
     ref64 = None
-    cfgs = [dict(waves_per_band_round=256, row_cap=78), dict(waves_per_band_round=128, row_cap=158),
-            dict(waves_per_band_round=512, row_cap=38)]
-    variants = [(c, d, split) for c in cfgs for d in ("8", "16") for split in (False, True)]
-    for cfg, depth, split in variants:
-        os.environ["LGCN_SWEEP_DEPTH"] = depth
-        os.environ["LGCN_SWEEP_LAUNCH_WAVES"] = str(8 * cfg["waves_per_band_round"]) if split else "0"
-        print(f"depth {depth} per-round launches {split}: ", end="")
+    cfgs = [dict(waves_per_band_round=256, row_cap=78),
+            dict(waves_per_band_round=2048, row_cap=78, sequential=1),
+            dict(n_bands=4, waves_per_band_round=2048, row_cap=78, sequential=1),
+            dict(n_bands=16, waves_per_band_round=2048, row_cap=78, sequential=1),
+            dict(n_bands=4, waves_per_band_round=2048, row_cap=78, sequential=1, piece_cap=128),
+            dict(n_bands=2, waves_per_band_round=2048, row_cap=78, sequential=1)]
+    for cfg in cfgs:
         t0 = time.perf_counter()
         sw = Operator.build(n, op.rowptr, op.entries, nu, n, 32, 256, sweep_cols=(0, nu))
         assert sw.sweep_cols is not None
