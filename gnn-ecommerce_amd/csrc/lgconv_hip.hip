@@ -611,7 +611,7 @@ __device__ __forceinline__ void tiles_body_dpp(const TileArgs &p, const int64_t 
     u4 nxt[L];
     int32_t nxt_rid = -1;
 #pragma unroll
-    for (int k = 0; k < L; ++k) nxt[k] = p.slab[(tile * L + k) * kWave + lane];
+    for (int k = 0; k < L; ++k) nxt[k] = __builtin_nontemporal_load(p.slab + (tile * L + k) * kWave + lane);
     if (l < B) nxt_rid = p.order[tile * R + (lane >> 4) * B + l];
     int32_t nxt_meta = p.meta[tile];
     for (; tile < tile_end; ++tile) {
@@ -622,7 +622,7 @@ __device__ __forceinline__ void tiles_body_dpp(const TileArgs &p, const int64_t 
         const int32_t meta = nxt_meta;
         if (tile + 1 < tile_end) {
 #pragma unroll
-            for (int k = 0; k < L; ++k) nxt[k] = p.slab[((tile + 1) * L + k) * kWave + lane];
+            for (int k = 0; k < L; ++k) nxt[k] = __builtin_nontemporal_load(p.slab + ((tile + 1) * L + k) * kWave + lane);
             if (l < B) nxt_rid = p.order[(tile + 1) * R + (lane >> 4) * B + l];
             nxt_meta = p.meta[tile + 1];
         }
@@ -692,7 +692,10 @@ __device__ __forceinline__ void tiles_body_dpp(const TileArgs &p, const int64_t 
             }
             const f4 o = {acc.v[0], acc.v[1], acc.v[2], acc.v[3]};
             // sc1 write-through: the output row is not read again in this launch (the host made sure of < 4 GiB)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o), ysrc, __umul24(row24, ys) + xoff, 0, 16);
+#ifndef LGC_STORE_AUX
+#define LGC_STORE_AUX 2     /* nt: output rows are not read again in this launch (sc1 569, plain 574, nt 561 us per hop) */
+#endif
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o), ysrc, __umul24(row24, ys) + xoff, 0, LGC_STORE_AUX);
         }
     }
 }
@@ -721,6 +724,9 @@ __global__ __launch_bounds__(kBlock) void k_rows_tile_dpp(TileArgs p) {
 //     entries (col = 0xFFFFFF, out of range: zeros) update a dummy LDS row;
 //   * at the end a wave writes its pieces to their partial slots (contiguous per output row, band-major) and
 //     k_spmm_combine adds a row's slots in that fixed order: deterministic, no float atomics.
+#ifndef LGC_SWEEP_GATHER_AUX
+#define LGC_SWEEP_GATHER_AUX 0
+#endif
 struct SweepArgs {
     const u4 *slabs;               // [n_slabs * 64]
     const int32_t *wave_slab_ptr;  // [n_waves + 1]
@@ -764,7 +770,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, DEPTH
     u4 nxt = p.slabs[(int64_t)slab * kWave + lane];
     for (; slab < slab_end; ++slab) {
         const u4 cur = nxt;
-        if (slab + 1 < slab_end) nxt = p.slabs[(int64_t)(slab + 1) * kWave + lane];
+        if (slab + 1 < slab_end) nxt = __builtin_nontemporal_load(p.slabs + (int64_t)(slab + 1) * kWave + lane);
         // 32 steps, DEPTH gathers in flight: issue step s + DEPTH after consuming step s
         f4 xv[DEPTH];
         int pk[DEPTH], vb[DEPTH];
@@ -772,7 +778,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, DEPTH
     {                                                                                                                  \
         sweep_fetch<((S) >> 1), ((S) & 1)>(cur, pk[(S) % DEPTH], vb[(S) % DEPTH]);                                     \
         xv[(S) % DEPTH] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(                                \
-            xsrc, __umul24(pk[(S) % DEPTH] & 0xFFFFFF, xs) + xoff, 0, 0));                                             \
+            xsrc, __umul24(pk[(S) % DEPTH] & 0xFFFFFF, xs) + xoff, 0, LGC_SWEEP_GATHER_AUX));                          \
     }
 #define LGC_CONSUME(S)                                                                                                 \
     {                                                                                                                  \
@@ -805,7 +811,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, DEPTH
         const f4 a = *reinterpret_cast<const f4 *>(mine + pc * 64);
         Acc<4> o;
         o.v[0] = a.x; o.v[1] = a.y; o.v[2] = a.z; o.v[3] = a.w;
-        store_row<4>(p.partials + (int64_t)slots[pc] * p.dim + c0, o);
+        const f4 t = {o.v[0], o.v[1], o.v[2], o.v[3]};
+        __builtin_nontemporal_store(t, reinterpret_cast<f4u *>(p.partials + (int64_t)slots[pc] * p.dim + c0));
     }
 }
 
