@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <algorithm>
 #include <new>
@@ -737,6 +738,7 @@ struct SweepArgs {
     int64_t x_stride;
     uint32_t x_bytes;
     int32_t dim, row_cap, n_waves, wave_begin;
+    unsigned long long *trace;     // diagnostics only (LGCN_SWEEP_TRACE): [n_waves, 16] s_memrealtime stamps per slab
 };
 
 template <int Q, int HALF>
@@ -767,7 +769,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, DEPTH
     int slab = p.wave_slab_ptr[w];
     const int slab_end = p.wave_slab_ptr[w + 1];
     if (slab >= slab_end) return;
-    u4 nxt = p.slabs[(int64_t)slab * kWave + lane];
+    u4 nxt = __builtin_nontemporal_load(p.slabs + (int64_t)slab * kWave + lane);
+    int tk = 0;
+    if (p.trace && lane == 0) p.trace[(int64_t)w * 16 + tk++] = __builtin_amdgcn_s_memrealtime();
     for (; slab < slab_end; ++slab) {
         const u4 cur = nxt;
         if (slab + 1 < slab_end) nxt = __builtin_nontemporal_load(p.slabs + (int64_t)(slab + 1) * kWave + lane);
@@ -804,6 +808,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, DEPTH
 #undef LGC_STEP
 #undef LGC_CONSUME
 #undef LGC_ISSUE
+        if (p.trace && lane == 0 && tk < 16) p.trace[(int64_t)w * 16 + tk++] = __builtin_amdgcn_s_memrealtime();
     }
     // write my pieces to their partial slots: lane group g takes pieces g, g + 4, ...
     const int32_t *slots = p.piece_slot + (int64_t)w * p.row_cap;
@@ -1776,7 +1781,8 @@ int lgc_spmm_sweep(const uint32_t *slabs, const int32_t *wave_slab_ptr, const in
     if (lds > 160 * 1024) return LGC_E_INVAL;
     if (n_waves > 0) {
         SweepArgs p{reinterpret_cast<const u4 *>(slabs), wave_slab_ptr, wave_npieces, piece_slot, x, partials, x_stride,
-                    (uint32_t)(((table_rows - 1) * x_stride + dim) * 4), dim, row_cap, (int32_t)n_waves, 0};
+                    (uint32_t)(((table_rows - 1) * x_stride + dim) * 4), dim, row_cap, (int32_t)n_waves, 0, nullptr};
+        if (const char *tr = getenv("LGCN_SWEEP_TRACE")) p.trace = reinterpret_cast<unsigned long long *>(strtoull(tr, nullptr, 0));
         static bool attr_set = false;
         if (!attr_set) {   // more than 64 KiB of dynamic LDS needs the opt-in once per process
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
