@@ -32,17 +32,14 @@ def timed(fn, reps=20, warm=3):
 
 
 def folded(op: Operator, base: int, span: int, m: int) -> Operator:
+    """The same rows with every gathered column of [base, base + span) folded onto m rows (plans rebuilt; the
+    chunk + tile path, no sweep: the point is the memory behaviour of the gathers)."""
     ent = op.entries.clone()
     col = ent[:, 0]
     sel = (col >= base) & (col < base + span)
     col[sel] = base + (col[sel] - base) % m
-    slab = None
-    if op.slab is not None:
-        slab = op.slab.clone()
-        c = slab[:, 0]
-        sel = (c >= base) & (c < base + span)
-        c[sel] = base + (c[sel] - base) % m
-    return Operator(op.n_rows, op.rowptr, ent, op.plan, slab, op.slab_width)
+    p = op.plan
+    return Operator.build(op.n_rows, op.rowptr, ent, p.row_begin, p.row_end, 32, 256)
 
 
 def main():
@@ -52,6 +49,7 @@ def main():
     ei, ew = g.coo(dev)
     pg = lg.PropGraph(ei, ew, g.num_nodes)
     user_op, item_op = pg.halves()
+    item_chunked = Operator.build(item_op.n_rows, item_op.rowptr, item_op.entries, g.n_users, g.num_nodes, 32, 256)
     x = synth.xavier_table(g.num_nodes, dim, 0, dev)
     y = torch.empty_like(x)
     nu, ni = g.n_users, g.n_items
@@ -59,7 +57,9 @@ def main():
     print(f"dim {dim}: item half gathers {g.nnz // 2} user rows ({nu * row_b / 1e6:.0f} MB table), "
           f"user half gathers {g.nnz // 2} item rows ({ni * row_b / 1e6:.1f} MB table)", flush=True)
     med, mn = timed(lambda: item_op.apply(x, y))
-    print(f"item half  full             : {med:8.1f} us (min {mn:.1f})", flush=True)
+    print(f"item half  full (product)   : {med:8.1f} us (min {mn:.1f})", flush=True)
+    med, mn = timed(lambda: item_chunked.apply(x, y))
+    print(f"item half  full (chunked)   : {med:8.1f} us (min {mn:.1f})", flush=True)
     med, mn = timed(lambda: user_op.apply(x, y))
     print(f"user half  full             : {med:8.1f} us (min {mn:.1f})", flush=True)
     med, mn = timed(lambda: user_op.apply(x, y, a=1.0, r=x, b=0.25))
@@ -70,7 +70,7 @@ def main():
         print(f"user half  items mod {m:7d} ({m * row_b / 1e6:7.2f} MB): {med:8.1f} us (min {mn:.1f})", flush=True)
         del op
     for m in (64, 4096, 12288, 65536, 262144, 786432):
-        op = folded(item_op, 0, nu, m)
+        op = folded(item_chunked, 0, nu, m)
         med, mn = timed(lambda: op.apply(x, y))
         print(f"item half  users mod {m:7d} ({m * row_b / 1e6:7.2f} MB): {med:8.1f} us (min {mn:.1f})", flush=True)
         del op
