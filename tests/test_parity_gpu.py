@@ -201,7 +201,9 @@ def test_golden_adam_steps_and_topk(device, name):
     d1, d1_ref = w1 - w0, t(z["weight_after_1"]) - w0
     d3, d3_ref = w3 - w0, t(z["weight_after_3"]) - w0
     assert rel_fro(w1, t(z["weight_after_1"])) <= TOL and rel_fro(w3, t(z["weight_after_3"])) <= TOL
-    assert rel_fro(d1, d1_ref) <= 1e-3 and rel_fro(d3, d3_ref) <= 1e-3
+    # measured 1e-6 .. 7e-6 (Adam turns a relative gradient error into the same relative error of the step, except
+    # where an element's gradient is within rounding of zero); 5e-5 leaves a factor of 7
+    assert rel_fro(d1, d1_ref) <= 5e-5 and rel_fro(d3, d3_ref) <= 5e-5, (rel_fro(d1, d1_ref), rel_fro(d3, d3_ref))
 
 
 @pytest.mark.parametrize("name", golden_names("edge_"))
