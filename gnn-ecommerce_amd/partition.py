@@ -74,9 +74,13 @@ class HipOps:
               keep_edge_values: bool = False) -> PropGraph:
         return PropGraph(edge_index, edge_weight, num_nodes, normalize, keep_edge_values=keep_edge_values)
 
-    def restrict(self, op: Operator, row_begin: int, row_end: int, short_max: int = SHORT_MAX) -> Operator:
-        """The same CSR, work plan limited to rows [row_begin, row_end)."""
-        return Operator.build(op.n_rows, op.rowptr, op.entries, row_begin, row_end, short_max, CHUNK_LEN)
+    def restrict(self, op: Operator, row_begin: int, row_end: int, short_max: int = SHORT_MAX,
+                 sweep_cols: Optional[Tuple[int, int]] = None) -> Operator:
+        """The same CSR, work plan limited to rows [row_begin, row_end).  ``sweep_cols``: the column range all entries
+        of those rows lie in (a rank's item rows only reference its own users) -- lets a large enough slice run as a
+        band sweep inside that range."""
+        return Operator.build(op.n_rows, op.rowptr, op.entries, row_begin, row_end, short_max, CHUNK_LEN,
+                              sweep_cols=sweep_cols)
 
     def apply(self, op: Operator, x: Tensor, out: Tensor, a: float, r: Optional[Tensor], b: float) -> None:
         op.apply(x, out, a=a, r=r, b=b)
@@ -113,12 +117,19 @@ class PartitionedPropagator:
         # A rank's slice of an item row is short (mean degree / world entries) but there are only n_items
         # of them: one wavefront per row (the chunk kernel, 16 gathers in flight) beats one lane group per
         # row there, so only rows that fit the slab stay on the short-row kernel.
-        self.item_op = self.ops.restrict(local.forward_op, n_users, n, ITEM_SHORT_MAX)
+        self.item_op = self._restrict_items(local.forward_op)
         self.local_nnz = int(mine.sum().item()) * 2
         self._keep = (full, local)
         self._coo = (edge_index, full.edge_values)
         self._transposed = None
         self._table_cache = {}
+
+    def _restrict_items(self, op):
+        """Item rows of a local operator: every column is one of this rank's own users."""
+        try:
+            return self.ops.restrict(op, self.n_users, self.num_nodes, ITEM_SHORT_MAX, sweep_cols=(self.u0, self.u1))
+        except TypeError:                                  # arithmetic test doubles without the sweep argument
+            return self.ops.restrict(op, self.n_users, self.num_nodes, ITEM_SHORT_MAX)
 
     # -- hops ----------------------------------------------------------------------------------
     # A hop has two local pieces and one exchange:
@@ -161,7 +172,7 @@ class PartitionedPropagator:
             g_user = self.ops.build(ei[:, own_src].contiguous(), vals[own_src].contiguous(), n, normalize=False)
             g_item = self.ops.build(ei[:, own_dst].contiguous(), vals[own_dst].contiguous(), n, normalize=False)
             self._transposed = (self.ops.restrict(g_user.transpose_op, self.u0, self.u1),
-                                self.ops.restrict(g_item.transpose_op, nu, n, ITEM_SHORT_MAX), g_user, g_item)
+                                self._restrict_items(g_item.transpose_op), g_user, g_item)
         return self._transposed[0], self._transposed[1]
 
     def _lincomb(self, y: Tensor, terms) -> None:
