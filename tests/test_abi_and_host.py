@@ -437,3 +437,25 @@ def test_sweep_plan_argument_errors():
                               1.0, 0.0, 64, None) == -1                              # waves not a multiple of 4
     assert lib.lgc_spmm_sweep(one, one, one, one, 8, 78, one, 4, None, 0, one, 1000, one, 64, ct.c_void_p(512), 64, None, 0,
                               1.0, 0.0, 90, None) == -2                              # width outside 61..64
+
+
+@pytest.mark.gpu
+def test_plain_c_host_drives_the_abi(tmp_path):
+    """tests/c_host/hop_host.c: no Python, no torch -- hipMalloc'd buffers, lgc_build_csr, lgc_spmm, lgc_build_tiles +
+    lgc_spmm_tiles from C, checked in C against the oracle's C restatement."""
+    import subprocess
+    if not torch.cuda.is_available():
+        pytest.skip("no ROCm device")
+    exe = str(tmp_path / "hop_host")
+    lib_dir = os.path.join(ROOT, "gnn-ecommerce_amd", "csrc")
+    ora_dir = os.path.join(ROOT, "oracle")
+    if not os.path.isfile(os.path.join(ora_dir, "liblgconv_ref.so")):
+        subprocess.run(["make", "-C", ora_dir], check=True)
+    cmd = ["gcc", "-O1", os.path.join(ROOT, "tests", "c_host", "hop_host.c"), "-I" + os.path.join(ROOT, "include"),
+           "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", os.path.join(lib_dir, "liblgconv_hip.so"),
+           os.path.join(ora_dir, "liblgconv_ref.so"), "-L/opt/rocm/lib", "-lamdhip64", "-lm",
+           "-Wl,-rpath," + lib_dir, "-Wl,-rpath," + ora_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    build = subprocess.run(cmd, capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and run.stdout.startswith("ok "), (run.returncode, run.stdout, run.stderr)
