@@ -589,6 +589,28 @@ __device__ __forceinline__ int bcast16(int v) {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+// (col, vb) = (colbits, valbits) of lane IDX of every DPP row; IDX is a compile-time constant after unrolling
+#define LGC_BCAST16(IDX, colbits, valbits, col, vb)                                                                    \
+    switch (IDX) {                                                                                                     \
+        case 0: col = bcast16<0>(colbits); vb = bcast16<0>(valbits); break;                                            \
+        case 1: col = bcast16<1>(colbits); vb = bcast16<1>(valbits); break;                                            \
+        case 2: col = bcast16<2>(colbits); vb = bcast16<2>(valbits); break;                                            \
+        case 3: col = bcast16<3>(colbits); vb = bcast16<3>(valbits); break;                                            \
+        case 4: col = bcast16<4>(colbits); vb = bcast16<4>(valbits); break;                                            \
+        case 5: col = bcast16<5>(colbits); vb = bcast16<5>(valbits); break;                                            \
+        case 6: col = bcast16<6>(colbits); vb = bcast16<6>(valbits); break;                                            \
+        case 7: col = bcast16<7>(colbits); vb = bcast16<7>(valbits); break;                                            \
+        case 8: col = bcast16<8>(colbits); vb = bcast16<8>(valbits); break;                                            \
+        case 9: col = bcast16<9>(colbits); vb = bcast16<9>(valbits); break;                                            \
+        case 10: col = bcast16<10>(colbits); vb = bcast16<10>(valbits); break;                                         \
+        case 11: col = bcast16<11>(colbits); vb = bcast16<11>(valbits); break;                                         \
+        case 12: col = bcast16<12>(colbits); vb = bcast16<12>(valbits); break;                                         \
+        case 13: col = bcast16<13>(colbits); vb = bcast16<13>(valbits); break;                                         \
+        case 14: col = bcast16<14>(colbits); vb = bcast16<14>(valbits); break;                                         \
+        default: col = bcast16<15>(colbits); vb = bcast16<15>(valbits); break;                                         \
+    }
+
+
 template <int W, int L>
 __device__ __forceinline__ void tiles_body_dpp(const TileArgs &p, const int64_t block) {
     constexpr int R = 128 * L / W;     // rows per tile
@@ -648,24 +670,7 @@ __device__ __forceinline__ void tiles_body_dpp(const TileArgs &p, const int64_t 
                             const int colbits = ((j0 + j) & 1) ? (int)cur[k].z : (int)cur[k].x;
                             const int valbits = ((j0 + j) & 1) ? (int)cur[k].w : (int)cur[k].y;
                             int col, vb;
-                            switch (bt * PPR + ((j0 + j) >> 1)) {   // compile-time after unrolling
-                                case 0: col = bcast16<0>(colbits); vb = bcast16<0>(valbits); break;
-                                case 1: col = bcast16<1>(colbits); vb = bcast16<1>(valbits); break;
-                                case 2: col = bcast16<2>(colbits); vb = bcast16<2>(valbits); break;
-                                case 3: col = bcast16<3>(colbits); vb = bcast16<3>(valbits); break;
-                                case 4: col = bcast16<4>(colbits); vb = bcast16<4>(valbits); break;
-                                case 5: col = bcast16<5>(colbits); vb = bcast16<5>(valbits); break;
-                                case 6: col = bcast16<6>(colbits); vb = bcast16<6>(valbits); break;
-                                case 7: col = bcast16<7>(colbits); vb = bcast16<7>(valbits); break;
-                                case 8: col = bcast16<8>(colbits); vb = bcast16<8>(valbits); break;
-                                case 9: col = bcast16<9>(colbits); vb = bcast16<9>(valbits); break;
-                                case 10: col = bcast16<10>(colbits); vb = bcast16<10>(valbits); break;
-                                case 11: col = bcast16<11>(colbits); vb = bcast16<11>(valbits); break;
-                                case 12: col = bcast16<12>(colbits); vb = bcast16<12>(valbits); break;
-                                case 13: col = bcast16<13>(colbits); vb = bcast16<13>(valbits); break;
-                                case 14: col = bcast16<14>(colbits); vb = bcast16<14>(valbits); break;
-                                default: col = bcast16<15>(colbits); vb = bcast16<15>(valbits); break;
-                            }
+                            LGC_BCAST16(bt * PPR + ((j0 + j) >> 1), colbits, valbits, col, vb)   // compile-time lane
                             val[j] = __int_as_float(vb);
                             xv[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, __umul24(col, xs) + xoff, 0, 0));
                         }
@@ -701,9 +706,103 @@ __device__ __forceinline__ void tiles_body_dpp(const TileArgs &p, const int64_t 
     }
 }
 
+// The same for rows of 68..128 columns (D = 80, 90, 96, 128): a row takes TWO DPP rows of a wavefront -- lanes
+// 0-15 its columns 0..63, lanes 16-31 the rest -- so a wave carries two rows per instruction and a 16-row tile takes
+// two passes.  Both DPP rows of a pair load the same 16 pieces of the tile, so the row_newbcast hand-out is
+// unchanged; lanes beyond the row's width use the out-of-range id for every load and store.
+template <int W, int L>
+__device__ __forceinline__ void tiles_body_dpp_wide(const TileArgs &p, const int64_t block) {
+    constexpr int R = 128 * L / W;     // rows per tile
+    constexpr int Wk = W / L;          // entries of a row in one load
+    constexpr int PPR = Wk / 2;        // 16-byte pieces of a row in one load
+    constexpr int B = R / 4;           // row slots per 16 pieces
+    static_assert(B * PPR == 16, "four row slots' pieces fill a DPP row");
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wave = block * (kBlock / kWave) + (threadIdx.x / kWave);
+    int64_t tile = __builtin_amdgcn_readfirstlane((int)(wave * p.tiles_per_wave));
+    if (tile >= p.n_tiles) return;  // wave-uniform
+    const int64_t tile_end = min(tile + (int64_t)p.tiles_per_wave, (int64_t)p.n_tiles);
+    const int l = lane & 15, pair = lane >> 5, half = (lane >> 4) & 1;
+    const int dim = p.part_dim[0];
+    const int rest = dim - 64;                                   // 4 .. 64 columns in the second DPP row
+    const bool lane_on = half == 0 || l * 4 < rest;              // ceil(rest / 4) lanes, the last one overlapping
+    const int c0 = half == 0 ? l * 4 : 64 + min(l * 4, rest - 4);
+    const unsigned xoff = (unsigned)c0 * 4u;
+    const int pad24 = 0xFFFFFF;
+    const auto xsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, p.x_bytes, 0x00020000);
+    const auto ysrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.y, 0, p.y_bytes, 0x00020000);
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.r, 0, p.r != nullptr ? p.r_bytes : 0u, 0x00020000);
+    const unsigned xs = (unsigned)p.x_stride * 4u, ys = (unsigned)p.y_stride * 4u, rs = (unsigned)p.r_stride * 4u;
+    for (; tile < tile_end; ++tile) {
+        const int32_t meta = p.meta[tile];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int quad = 2 * pass + pair;                    // which 16 pieces / which B row slots of the tile
+            u4 cur[L];
+#pragma unroll
+            for (int k = 0; k < L; ++k) cur[k] = __builtin_nontemporal_load(p.slab + (tile * L + k) * kWave + quad * 16 + l);
+            int32_t cur_rid = -1;
+            if (l < B) cur_rid = p.order[tile * R + quad * B + l];
+#pragma unroll
+            for (int bt = 0; bt < B; ++bt) {
+                const int nmax = (meta >> (8 * bt)) & 0xFF;   // scalar (an upper bound: the longest of four slots)
+                int row24 = bt == 0 ? bcast16<0>(cur_rid) : bt == 1 ? bcast16<1>(cur_rid)
+                            : bt == 2 ? bcast16<2>(cur_rid) : bcast16<3>(cur_rid);
+                row24 = lane_on ? row24 : pad24;
+                f2 a0 = {0.0f, 0.0f}, a1 = {0.0f, 0.0f};
+                f4 rv = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (p.r != nullptr)
+                    rv = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, __umul24(row24, rs) + xoff, 0, 0));
+#pragma unroll
+                for (int k = 0; k < L; ++k) {
+#pragma unroll
+                    for (int j0 = 0; j0 < Wk; j0 += 4) {
+                        if (k * Wk + j0 < nmax) {     // wave-uniform
+                            f4 xv[4];
+                            float val[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int colbits = ((j0 + j) & 1) ? (int)cur[k].z : (int)cur[k].x;
+                                const int valbits = ((j0 + j) & 1) ? (int)cur[k].w : (int)cur[k].y;
+                                int col, vb;
+                                LGC_BCAST16(bt * PPR + ((j0 + j) >> 1), colbits, valbits, col, vb)
+                                col = lane_on ? col : pad24;
+                                val[j] = __int_as_float(vb);
+                                xv[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, __umul24(col, xs) + xoff, 0, 0));
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {   // product rounded, then added (no FMA: -ffp-contract=off)
+                                const f2 v2 = {val[j], val[j]};
+                                const f2 lo = {xv[j].x, xv[j].y}, hi = {xv[j].z, xv[j].w};
+                                a0 = a0 + lo * v2;
+                                a1 = a1 + hi * v2;
+                            }
+                        }
+                    }
+                }
+                Acc<4> acc;
+                acc.v[0] = a0.x; acc.v[1] = a0.y; acc.v[2] = a1.x; acc.v[3] = a1.y;
+                if (p.a != 1.0f) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc.v[i] = __fmul_rn(p.a, acc.v[i]);
+                }
+                if (p.r != nullptr) {
+                    acc.v[0] = __fadd_rn(acc.v[0], __fmul_rn(p.b, rv.x));
+                    acc.v[1] = __fadd_rn(acc.v[1], __fmul_rn(p.b, rv.y));
+                    acc.v[2] = __fadd_rn(acc.v[2], __fmul_rn(p.b, rv.z));
+                    acc.v[3] = __fadd_rn(acc.v[3], __fmul_rn(p.b, rv.w));
+                }
+                const f4 o = {acc.v[0], acc.v[1], acc.v[2], acc.v[3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o), ysrc, __umul24(row24, ys) + xoff, 0, LGC_STORE_AUX);
+            }
+        }
+    }
+}
+
 template <int W, int L>
 __global__ __launch_bounds__(kBlock) void k_rows_tile_dpp(TileArgs p) {
-    tiles_body_dpp<W, L>(p, blockIdx.x);
+    if (p.part_dim[0] > 64) tiles_body_dpp_wide<W, L>(p, blockIdx.x);
+    else tiles_body_dpp<W, L>(p, blockIdx.x);
 }
 
 
@@ -833,7 +932,7 @@ struct FusedArgs {
     int32_t width[3], blocks[3];
 };
 
-template <bool FAST>
+template <int MODE>   // 0: generic tiles, 1: DPP fast path (61..64 columns), 2: DPP fast path, two DPP rows per row (68..128)
 __global__ __launch_bounds__(kBlock) void k_apply_fused(FusedArgs f) {
     int64_t b = blockIdx.x;
     if (b < f.chunk_blocks) {
@@ -845,7 +944,11 @@ __global__ __launch_bounds__(kBlock) void k_apply_fused(FusedArgs f) {
     for (int c = 0; c < 3; ++c) {
         if (c >= f.n_classes) return;
         if (b < f.blocks[c]) {
-            if constexpr (FAST) {
+            if constexpr (MODE == 2) {
+                if (f.width[c] == 8) tiles_body_dpp_wide<8, 1>(f.t[c], b);
+                else if (f.width[c] == 16) tiles_body_dpp_wide<16, 1>(f.t[c], b);
+                else tiles_body_dpp_wide<32, 2>(f.t[c], b);
+            } else if constexpr (MODE == 1) {
                 if (f.width[c] == 8) tiles_body_dpp<8, 1>(f.t[c], b);
                 else if (f.width[c] == 16) tiles_body_dpp<16, 1>(f.t[c], b);
                 else tiles_body_dpp<32, 2>(f.t[c], b);
@@ -1548,7 +1651,8 @@ int prepare_tiles(TilePrep &out, const int32_t *order, const int32_t *meta, cons
         const uint32_t pad = (uint32_t)(0xFFFFFFull * (uint64_t)(stride * 4));
         return stride * 4 < (1 << 24) && table_bytes(stride) < (int64_t(1) << 32) && (int64_t)pad >= table_bytes(stride);
     };
-    out.fast = meta != nullptr && parts == 1 && dim >= 61 && dim <= 64 && table_rows > 0 && table_rows < 0xFFFFFF &&
+    out.fast = meta != nullptr && parts == 1 && ((dim >= 61 && dim <= 64) || (dim >= 68 && dim <= 128)) && table_rows > 0 &&
+               table_rows < 0xFFFFFF &&
                pad_is_oob(x_stride) && pad_is_oob(y_stride) && (!r || pad_is_oob(r_stride)) &&
                getenv("LGCN_NO_FAST_TILES") == nullptr;
     if (out.fast) {
@@ -1859,8 +1963,9 @@ int lgc_apply(const lgc_operator *op, int64_t table_rows, const float *x, int64_
         }
         hipStream_t st = as_stream(stream);
         if (total > 0) {
-            if (fast) hipLaunchKernelGGL((k_apply_fused<true>), dim3((unsigned)total), dim3(kBlock), 0, st, f);
-            else hipLaunchKernelGGL((k_apply_fused<false>), dim3((unsigned)total), dim3(kBlock), 0, st, f);
+            if (fast && dim > 64) hipLaunchKernelGGL((k_apply_fused<2>), dim3((unsigned)total), dim3(kBlock), 0, st, f);
+            else if (fast) hipLaunchKernelGGL((k_apply_fused<1>), dim3((unsigned)total), dim3(kBlock), 0, st, f);
+            else hipLaunchKernelGGL((k_apply_fused<0>), dim3((unsigned)total), dim3(kBlock), 0, st, f);
         }
         if (op->n_multi > 0)
             hipLaunchKernelGGL((k_spmm_combine<4>), dim3(ceil_div(op->n_multi, kBlock / kWave)), dim3(kBlock), 0, st, f.sp, op->multi,

@@ -118,8 +118,8 @@ int lgc_build_csr(const int64_t *edge_index, const float *edge_weight,
  *            (16 for width 8, 8 for width 16 and 32); every listed row must have at most `width` entries.
  *            Slot g * (R/4) + bt of a tile is processed by lane group g in batch bt.
  *   meta     int32 [n_tiles]: byte bt = the largest entry count among the four rows of batch bt (upper bounds
- *            are allowed), or NULL.  With meta, a 61..64-wide table and tables below 4 GiB the kernel takes the
- *            path without divergent control flow (DPP broadcasts, buffer addressing); otherwise a generic one.
+ *            are allowed), or NULL.  With meta, a 61..64- or 68..128-wide table and tables below 4 GiB the kernel takes
+ *            the path without divergent control flow (DPP broadcasts, buffer addressing); otherwise a generic one.
  *   width    8, 16 or 32 entries per row
  *   parts    1, or 2 (dim a multiple of 8; meant for dim*4 a multiple of 256 bytes, generic path only): the two
  *            column halves of every row are computed by workgroups on different XCDs, halving the bytes of the

@@ -556,7 +556,7 @@ def test_end_to_end_caller_loop_learns(device):
     assert log[-1]["R@20"] > 4 * chance and log[-1]["R@20"] >= log[0]["R@20"] - 0.02
 
 
-@pytest.mark.parametrize("dim", [64, 63, 61, 60, 90, 16, 7, 4, 128])
+@pytest.mark.parametrize("dim", [64, 63, 61, 60, 90, 16, 7, 4, 128, 68, 80, 96, 101, 67])
 def test_tiled_rows_are_bit_identical_to_the_row_pointer_path(device, dim, monkeypatch):
     """lgc_spmm_tiles (processing order, 1 KiB tiles, DPP fast path at 61..64) vs lgc_spmm's plain row part:
     same entries in the same order, products rounded before the add -> the same bits, with and without epilogue."""
