@@ -26,13 +26,13 @@ ST_SAMPLER_EXHAUSTED = 2
 class SweepCfg(Structure):
     """lgc_sweep_cfg"""
     _fields_ = [("n_bands", c_int32), ("waves_per_band_round", c_int32), ("row_cap", c_int32), ("piece_cap", c_int32),
-                ("lookahead", c_int32), ("sequential", c_int32)]
+                ("lookahead", c_int32), ("sequential", c_int32), ("groups", c_int32)]
 
 
 class SweepDims(Structure):
     """lgc_sweep_dims"""
     _fields_ = [("n_bands", c_int32), ("rounds", c_int32), ("row_cap", c_int32), ("piece_cap", c_int32),
-                ("n_rows", c_int32), ("reserved", c_int32),
+                ("n_rows", c_int32), ("groups", c_int32),
                 ("n_waves", c_int64), ("n_slabs", c_int64), ("n_slots", c_int64), ("n_entries", c_int64),
                 ("n_steps", c_int64), ("n_padding", c_int64)]
 
@@ -46,7 +46,7 @@ class SweepArraysC(Structure):
     """lgc_sweep_arrays"""
     _fields_ = [("slabs", c_void_p), ("wave_slab_ptr", c_void_p), ("wave_npieces", c_void_p), ("piece_slot", c_void_p),
                 ("multi", c_void_p), ("multi_wide", c_void_p), ("partials", c_void_p), ("n_waves", c_int64),
-                ("row_cap", c_int32), ("n_rows", c_int32), ("n_wide", c_int32), ("reserved", c_int32)]
+                ("row_cap", c_int32), ("n_rows", c_int32), ("n_wide", c_int32), ("groups", c_int32)]
 
 
 class OperatorC(Structure):
@@ -80,7 +80,7 @@ SIGNATURES = {
     "lgc_sweep_plan_export": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lgc_sweep_plan_free": (None, [c_void_p]),
     "lgc_sweep_ok": (c_int, [c_int32, c_int64, c_int64]),
-    "lgc_spmm_sweep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int32, c_void_p,
+    "lgc_spmm_sweep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p,
                                c_int32, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float, c_float,
                                c_int32, c_void_p]),
     "lgc_apply": (c_int, [POINTER(OperatorC), c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float, c_float,

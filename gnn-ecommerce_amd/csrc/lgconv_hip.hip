@@ -989,6 +989,83 @@ __global__ void k_build_tiles(const int32_t *__restrict__ rowptr, const lgc_entr
 }
 
 
+// The band sweep for tables of 68..96 columns (D = 80, 90): a table row takes two DPP rows (lanes 0-15 columns 0..63,
+// lanes 16-31 the rest), a wavefront gathers two rows per instruction, a step has two entries, a slab is 512 bytes
+// (both DPP rows of a pair load the same 16 pieces), and an accumulator is 96 floats: 51 per wavefront, five rounds.
+constexpr int kWideRow = 96;   // floats per LDS accumulator row
+
+template <int DEPTH>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 8))) void k_sweep_wide(SweepArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wib = threadIdx.x / kWave;
+    const int w = __builtin_amdgcn_readfirstlane((int)(p.wave_begin + blockIdx.x * (kBlock / kWave) + wib));
+    if (w >= p.n_waves) return;
+    const int npieces = p.wave_npieces[w];
+    if (npieces == 0) return;  // wave-uniform
+    const int l = lane & 15, pair = lane >> 5, half = (lane >> 4) & 1;
+    const int rest = p.dim - 64;                                  // 4 .. 32 columns in the second DPP row
+    const bool lane_on = half == 0 || l * 4 < rest;               // lanes that own columns of the table
+    const bool lds_on = half == 0 || l < (kWideRow - 64) / 4;     // lanes that own a slice of the accumulator row
+    const int c0 = half == 0 ? l * 4 : 64 + min(l * 4, rest - 4);
+    float *acc = lds + (size_t)wib * (p.row_cap + 1) * kWideRow;  // row `row_cap` = dummy
+    {
+        const f4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int i = lane; i < (p.row_cap + 1) * (kWideRow / 4); i += kWave) *reinterpret_cast<f4 *>(acc + i * 4) = z;
+    }
+    const auto xsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, p.x_bytes, 0x00020000);
+    const unsigned xs = (unsigned)p.x_stride * 4u, xoff = (unsigned)c0 * 4u;
+    float *mine = acc + half * 64 + (lds_on ? l * 4 : 0);        // + piece * kWideRow
+    int slab = p.wave_slab_ptr[w];
+    const int slab_end = p.wave_slab_ptr[w + 1];
+    if (slab >= slab_end) return;
+    // a 512-byte slab = 32 pieces; lanes of pair g read pieces 16 g + l (both of its DPP rows the same ones)
+    const int piece_lane = pair * 16 + l;
+    u4 nxt = __builtin_nontemporal_load(p.slabs + (int64_t)slab * 32 + piece_lane);
+    for (; slab < slab_end; ++slab) {
+        const u4 cur = nxt;
+        if (slab + 1 < slab_end) nxt = __builtin_nontemporal_load(p.slabs + (int64_t)(slab + 1) * 32 + piece_lane);
+        f4 xv[DEPTH];
+        int pk[DEPTH], vb[DEPTH];
+#define LGC_ISSUE(S)                                                                                                   \
+    {                                                                                                                  \
+        sweep_fetch<((S) >> 1), ((S) & 1)>(cur, pk[(S) % DEPTH], vb[(S) % DEPTH]);                                     \
+        const int col_ = lane_on ? (pk[(S) % DEPTH] & 0xFFFFFF) : 0xFFFFFF;                                            \
+        xv[(S) % DEPTH] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(                                \
+            xsrc, __umul24(col_, xs) + xoff, 0, LGC_SWEEP_GATHER_AUX));                                                \
+    }
+#define LGC_CONSUME(S)                                                                                                 \
+    if (lds_on) {                                                                                                      \
+        float *row = mine + ((unsigned)pk[(S) % DEPTH] >> 24) * kWideRow;                                              \
+        f4 a = *reinterpret_cast<f4 *>(row);                                                                           \
+        const float v = __int_as_float(vb[(S) % DEPTH]);                                                               \
+        const f2 v2 = {v, v};                                                                                          \
+        const f2 lo = {xv[(S) % DEPTH].x, xv[(S) % DEPTH].y}, hi = {xv[(S) % DEPTH].z, xv[(S) % DEPTH].w};             \
+        const f2 alo = f2{a.x, a.y} + lo * v2, ahi = f2{a.z, a.w} + hi * v2;                                           \
+        *reinterpret_cast<f4 *>(row) = f4{alo.x, alo.y, ahi.x, ahi.y};                                                 \
+    }
+#define LGC_STEP(S)                                                                                                    \
+    LGC_CONSUME(S)                                                                                                     \
+    if constexpr ((S) + DEPTH < 32) LGC_ISSUE((S) + DEPTH)
+        LGC_ISSUE(0) LGC_ISSUE(1) LGC_ISSUE(2) LGC_ISSUE(3) LGC_ISSUE(4) LGC_ISSUE(5) LGC_ISSUE(6) LGC_ISSUE(7)
+        LGC_STEP(0) LGC_STEP(1) LGC_STEP(2) LGC_STEP(3) LGC_STEP(4) LGC_STEP(5) LGC_STEP(6) LGC_STEP(7)
+        LGC_STEP(8) LGC_STEP(9) LGC_STEP(10) LGC_STEP(11) LGC_STEP(12) LGC_STEP(13) LGC_STEP(14) LGC_STEP(15)
+        LGC_STEP(16) LGC_STEP(17) LGC_STEP(18) LGC_STEP(19) LGC_STEP(20) LGC_STEP(21) LGC_STEP(22) LGC_STEP(23)
+        LGC_STEP(24) LGC_STEP(25) LGC_STEP(26) LGC_STEP(27) LGC_STEP(28) LGC_STEP(29) LGC_STEP(30) LGC_STEP(31)
+#undef LGC_STEP
+#undef LGC_CONSUME
+#undef LGC_ISSUE
+    }
+    // write my pieces to their partial slots: pair g takes pieces g, g + 2, ...
+    const int32_t *slots = p.piece_slot + (int64_t)w * p.row_cap;
+    for (int pc = pair; pc < npieces; pc += 2) {
+        if (lane_on) {
+            const f4 a = *reinterpret_cast<const f4 *>(mine + pc * kWideRow);
+            __builtin_nontemporal_store(a, reinterpret_cast<f4u *>(p.partials + (int64_t)slots[pc] * p.dim + c0));
+        }
+    }
+}
+
 // Sum of a swept row's partial slots + epilogue, one launch:
 //   blocks [0, n_wide)   rows cut into many pieces (hubs): one WORKGROUP per row -- unit (wave, lane group) u of 16
 //                        adds slots u, u + 16, ... (4 loads in flight), then groups are added in order inside the
@@ -1430,6 +1507,8 @@ void parallel_for(int64_t n, F &&f) {
 int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin, int32_t row_end,
                      int32_t col_lo, int32_t col_hi, const lgc_sweep_cfg &cfg) {
     const int NB = cfg.n_bands, WPBR = cfg.waves_per_band_round, CAP = cfg.row_cap;
+    const int GROUPS = cfg.groups == 2 ? 2 : 4;          // entries per step = rows a wavefront gathers per instruction
+    const int SLAB = 64 * GROUPS;                        // dwords per 32-step slab: 1 KiB (4 groups) or 512 B (2)
     const int64_t e0 = rowptr[row_begin], e1 = rowptr[row_end];
     const int64_t ne = e1 - e0;
     const int32_t n_rows = row_end - row_begin;
@@ -1553,11 +1632,11 @@ int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry 
                 if (head >= items.size()) break;
                 if (step % 32 == 0) {
                     const size_t base = out.size();
-                    out.resize(base + 256);
-                    for (int i = 0; i < 128; ++i) { out[base + 2 * i] = PAD_X; out[base + 2 * i + 1] = 0u; }
+                    out.resize(base + SLAB);
+                    for (int i = 0; i < SLAB / 2; ++i) { out[base + 2 * i] = PAD_X; out[base + 2 * i + 1] = 0u; }
                 }
                 int used[4], n_used = 0, seen = 0;
-                for (size_t i = head; n_used < 4 && i < items.size() && seen < cfg.lookahead; ++i) {
+                for (size_t i = head; n_used < GROUPS && i < items.size() && seen < cfg.lookahead; ++i) {
                     if (done[i]) continue;
                     ++seen;
                     bool clash = false;
@@ -1568,13 +1647,13 @@ int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry 
                     done[i] = 1;
                     const int sl = (int)(step % 32);
                     // lane 16 g + (s >> 1), component pair (s & 1): dword (16 g + (s >> 1)) * 4 + 2 (s & 1) of the slab
-                    const size_t at = (out.size() - 256) + (size_t)((16 * grp + (sl >> 1)) * 4 + 2 * (sl & 1));
+                    const size_t at = (out.size() - SLAB) + (size_t)((16 * grp + (sl >> 1)) * 4 + 2 * (sl & 1));
                     uint32_t vbits;
                     memcpy(&vbits, &items[i].val, 4);
                     out[at] = ((uint32_t)items[i].col & 0xFFFFFFu) | ((uint32_t)items[i].piece << 24);
                     out[at + 1] = vbits;
                 }
-                pad += 4 - n_used;
+                pad += GROUPS - n_used;
                 ++step;
             }
             wave_steps[(size_t)w] = step;
@@ -1584,25 +1663,26 @@ int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry 
     pl.wave_slab_ptr.assign((size_t)n_waves + 1, 0);
     int64_t total = 0, n_steps_total = 0, n_pad = 0;
     for (int64_t w = 0; w < n_waves; ++w) {
-        pl.wave_slab_ptr[(size_t)w] = (int32_t)(total / 256);
+        pl.wave_slab_ptr[(size_t)w] = (int32_t)(total / SLAB);
         total += (int64_t)wave_slabs[(size_t)w].size();
         n_steps_total += wave_steps[(size_t)w];
         n_pad += wave_pad[(size_t)w];
     }
-    if (total / 256 >= INT32_MAX) return LGC_E_RANGE;
-    pl.wave_slab_ptr[(size_t)n_waves] = (int32_t)(total / 256);
+    if (total / SLAB >= INT32_MAX) return LGC_E_RANGE;
+    pl.wave_slab_ptr[(size_t)n_waves] = (int32_t)(total / SLAB);
     pl.slabs.resize((size_t)total);
     parallel_for(n_waves, [&](int64_t wlo, int64_t whi) {
         for (int64_t w = wlo; w < whi; ++w)
             std::copy(wave_slabs[(size_t)w].begin(), wave_slabs[(size_t)w].end(),
-                      pl.slabs.begin() + (size_t)pl.wave_slab_ptr[(size_t)w] * 256);
+                      pl.slabs.begin() + (size_t)pl.wave_slab_ptr[(size_t)w] * SLAB);
     });
     pl.dims.n_bands = NB;
     pl.dims.rounds = rounds;
     pl.dims.row_cap = CAP;
     pl.dims.piece_cap = PCAP;
     pl.dims.n_waves = n_waves;
-    pl.dims.n_slabs = total / 256;
+    pl.dims.n_slabs = total / SLAB;
+    pl.dims.groups = GROUPS;
     pl.dims.n_slots = n_pieces;
     pl.dims.n_rows = n_rows;
     pl.dims.n_entries = ne;
@@ -1824,7 +1904,7 @@ lgc_sweep_plan *lgc_sweep_plan_create(const int32_t *rowptr_host, const lgc_entr
     if (rowptr_host && (entries_host || rowptr_host[row_end] == rowptr_host[row_begin]) && cfg && row_begin >= 0 &&
         row_end >= row_begin && col_lo >= 0 && col_hi > col_lo && col_hi <= 0xFFFFFF && cfg->n_bands >= 1 &&
         cfg->n_bands <= 64 && cfg->waves_per_band_round >= 4 && cfg->waves_per_band_round % 4 == 0 && cfg->row_cap >= 1 &&
-        cfg->row_cap <= 254 && cfg->piece_cap >= 1 && cfg->lookahead >= 4) {
+        cfg->row_cap <= 254 && cfg->piece_cap >= 1 && cfg->lookahead >= 4 && (cfg->groups == 0 || cfg->groups == 2 || cfg->groups == 4)) {
         pl = new (std::nothrow) lgc_sweep_plan();
         if (pl) {
             try {
@@ -1861,14 +1941,15 @@ int lgc_sweep_plan_export(const lgc_sweep_plan *plan, uint32_t *slabs, int32_t *
 void lgc_sweep_plan_free(lgc_sweep_plan *plan) { delete plan; }
 
 int lgc_sweep_ok(int32_t dim, int64_t table_rows, int64_t x_stride) {
-    if (dim < 61 || dim > 64 || table_rows <= 0 || table_rows >= 0xFFFFFF || x_stride < dim) return 0;
+    const int groups = (dim >= 61 && dim <= 64) ? 4 : (dim >= 68 && dim <= kWideRow) ? 2 : 0;
+    if (groups == 0 || table_rows <= 0 || table_rows >= 0xFFFFFF || x_stride < dim) return 0;
     const int64_t bytes = ((table_rows - 1) * x_stride + dim) * 4;
     const uint32_t pad = (uint32_t)(0xFFFFFFull * (uint64_t)(x_stride * 4));
-    return (x_stride * 4 < (1 << 24) && bytes < (int64_t(1) << 32) && (int64_t)pad >= bytes) ? 1 : 0;
+    return (x_stride * 4 < (1 << 24) && bytes < (int64_t(1) << 32) && (int64_t)pad >= bytes) ? groups : 0;
 }
 
 int lgc_spmm_sweep(const uint32_t *slabs, const int32_t *wave_slab_ptr, const int32_t *wave_npieces, const int32_t *piece_slot,
-                   int64_t n_waves, int32_t row_cap, const lgc_multi_row *multi, int32_t n_rows,
+                   int64_t n_waves, int32_t row_cap, int32_t groups, const lgc_multi_row *multi, int32_t n_rows,
                    const lgc_multi_row *multi_wide, int32_t n_wide, float *partials,
                    int64_t table_rows, const float *x, int64_t x_stride, float *y, int64_t y_stride, const float *r,
                    int64_t r_stride, float a, float b, int32_t dim, void *stream_) {
@@ -1876,12 +1957,13 @@ int lgc_spmm_sweep(const uint32_t *slabs, const int32_t *wave_slab_ptr, const in
         n_waves % 4 != 0 || n_rows < 0 || n_wide < 0 || (n_rows > 0 && !multi) || (n_wide > 0 && !multi_wide) || row_cap < 1 ||
         row_cap > 254 || x == y)
         return LGC_E_INVAL;
-    if (!lgc_sweep_ok(dim, table_rows, x_stride)) return LGC_E_DIM;
+    if (groups == 0) groups = 4;
+    if (lgc_sweep_ok(dim, table_rows, x_stride) != groups) return LGC_E_DIM;    // the plan's step width must fit the table
     if (y_stride < dim || (r && r_stride < dim)) return LGC_E_INVAL;
     if (!aligned_to(x, 4) || !aligned_to(y, 4) || (r && !aligned_to(r, 4)) || !aligned_to(slabs, 16) || !aligned_to(partials, 16))
         return LGC_E_ALIGN;
     hipStream_t stream = as_stream(stream_);
-    const size_t lds = (size_t)(kBlock / kWave) * (size_t)(row_cap + 1) * 64 * sizeof(float);
+    const size_t lds = (size_t)(kBlock / kWave) * (size_t)(row_cap + 1) * (groups == 2 ? kWideRow : 64) * sizeof(float);
     if (lds > 160 * 1024) return LGC_E_INVAL;
     if (n_waves > 0) {
         SweepArgs p{reinterpret_cast<const u4 *>(slabs), wave_slab_ptr, wave_npieces, piece_slot, x, partials, x_stride,
@@ -1894,6 +1976,9 @@ int lgc_spmm_sweep(const uint32_t *slabs, const int32_t *wave_slab_ptr, const in
             if (e == hipSuccess)
                 e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         160 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_wide<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        160 * 1024);
             if (e != hipSuccess) return (int)e;
             attr_set = true;
         }
@@ -1903,7 +1988,8 @@ int lgc_spmm_sweep(const uint32_t *slabs, const int32_t *wave_slab_ptr, const in
         for (int64_t w0 = 0; w0 < n_waves; w0 += per_launch) {
             p.wave_begin = (int32_t)w0;
             const unsigned blocks = (unsigned)(std::min<int64_t>(per_launch, n_waves - w0) / 4);
-            if (depth == 16) hipLaunchKernelGGL(k_sweep<16>, dim3(blocks), dim3(kBlock), lds, stream, p);
+            if (groups == 2) hipLaunchKernelGGL(k_sweep_wide<8>, dim3(blocks), dim3(kBlock), lds, stream, p);
+            else if (depth == 16) hipLaunchKernelGGL(k_sweep<16>, dim3(blocks), dim3(kBlock), lds, stream, p);
             else hipLaunchKernelGGL(k_sweep<8>, dim3(blocks), dim3(kBlock), lds, stream, p);
         }
     }
@@ -1922,10 +2008,10 @@ int lgc_spmm_sweep(const uint32_t *slabs, const int32_t *wave_slab_ptr, const in
 int lgc_apply(const lgc_operator *op, int64_t table_rows, const float *x, int64_t x_stride, float *y, int64_t y_stride,
               const float *r, int64_t r_stride, float a, float b, int32_t dim, void *stream) {
     if (!op || op->n_tile_classes < 0 || op->n_tile_classes > 3) return LGC_E_INVAL;
-    if (op->sweep && lgc_sweep_ok(dim, table_rows, x_stride)) {
+    if (op->sweep && lgc_sweep_ok(dim, table_rows, x_stride) == (op->sweep->groups ? op->sweep->groups : 4)) {
         const lgc_sweep_arrays *sw = op->sweep;
         return lgc_spmm_sweep(sw->slabs, sw->wave_slab_ptr, sw->wave_npieces, sw->piece_slot, sw->n_waves, sw->row_cap,
-                              sw->multi, sw->n_rows, sw->multi_wide, sw->n_wide, sw->partials, table_rows, x, x_stride, y,
+                              sw->groups, sw->multi, sw->n_rows, sw->multi_wide, sw->n_wide, sw->partials, table_rows, x, x_stride, y,
                               y_stride, r, r_stride, a, b, dim, stream);
     }
     const bool tiled = op->n_tile_classes > 0 && dim >= 4;

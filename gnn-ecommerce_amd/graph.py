@@ -49,7 +49,10 @@ SWEEP_CFG = dict(n_bands=int(os.environ.get("LGCN_SWEEP_BANDS", "8")), waves_per
                  row_cap=int(os.environ.get("LGCN_SWEEP_ROW_CAP", "78")),
                  piece_cap=int(os.environ.get("LGCN_SWEEP_PIECE_CAP", "64")),
                  lookahead=int(os.environ.get("LGCN_SWEEP_LOOKAHEAD", "64")),
-                 sequential=int(os.environ.get("LGCN_SWEEP_SEQUENTIAL", "0")))
+                 sequential=int(os.environ.get("LGCN_SWEEP_SEQUENTIAL", "0")), groups=4)
+SWEEP_WIDE = os.environ.get("LGCN_SWEEP_WIDE", "1") == "1"
+# tables of 68..96 columns: a row takes two DPP rows, LDS rows are 96 floats -> 51 accumulators per wavefront
+SWEEP_CFG_WIDE = dict(SWEEP_CFG, row_cap=int(os.environ.get("LGCN_SWEEP_ROW_CAP_WIDE", "51")), groups=2)
 
 
 @dataclass
@@ -218,7 +221,7 @@ def sweep_plan_host(rowptr: Tensor, entries: Tensor, row_begin: int, row_end: in
         d = _native.SweepDims()
         _native.check(lib.lgc_sweep_plan_dims(handle, ctypes.byref(d)), "lgc_sweep_plan_dims")
         dims = {k: getattr(d, k) for k, _ in _native.SweepDims._fields_}
-        arrays = {"slabs": torch.empty(max(d.n_slabs, 1) * 256, dtype=torch.int32),
+        arrays = {"slabs": torch.empty(max(d.n_slabs, 1) * 64 * d.groups, dtype=torch.int32),
                   "wave_slab_ptr": torch.empty(d.n_waves + 1, dtype=torch.int32),
                   "wave_npieces": torch.empty(max(d.n_waves, 1), dtype=torch.int32),
                   "piece_slot": torch.empty(max(d.n_waves * d.row_cap, 1), dtype=torch.int32),
@@ -276,7 +279,7 @@ class Operator:
     plan: RowPlan
     tiled: bool = False                  # rows up to plan.short_max go through the tiled kernels
     sweep_cols: Optional[Tuple[int, int]] = None    # column range of a bipartite half that qualifies for the band sweep
-    _sweep: Optional[SweepPlan] = None
+    _sweep: Dict[int, SweepPlan] = field(default_factory=dict)     # by entries per step: 4 (61..64 columns), 2 (68..96)
     _tiles: Optional[List[TileClass]] = None
     _partials: Dict[int, Tensor] = field(default_factory=dict)
     _c_structs: Dict[tuple, list] = field(default_factory=dict)
@@ -307,14 +310,22 @@ class Operator:
                 op.sweep_cols = (int(sweep_cols[0]), int(sweep_cols[1]))
         return op
 
-    @property
-    def sweep(self) -> Optional[SweepPlan]:
+    def sweep_plan(self, groups: int = 4) -> Optional[SweepPlan]:
+        """The band-sweep plan for tables whose rows take 64 / groups lanes... i.e. 4 rows (61..64 columns) or 2 rows
+        (68..96 columns) per gather instruction; built on first use."""
         if self.sweep_cols is None:
             return None
-        if self._sweep is None:
+        plan = self._sweep.get(groups)
+        if plan is None:
             p = self.plan
-            self._sweep = SweepPlan(self.rowptr, self.entries, p.row_begin, p.row_end, *self.sweep_cols)
-        return self._sweep
+            plan = SweepPlan(self.rowptr, self.entries, p.row_begin, p.row_end, *self.sweep_cols,
+                             cfg=SWEEP_CFG_WIDE if groups == 2 else SWEEP_CFG)
+            self._sweep[groups] = plan
+        return plan
+
+    @property
+    def sweep(self) -> Optional[SweepPlan]:
+        return self.sweep_plan(4)
 
     @property
     def tiles(self) -> List[TileClass]:
@@ -344,7 +355,7 @@ class Operator:
     def columns(self) -> Tensor:
         return self.entries[:, 0]
 
-    def c_struct(self, dim: int, sweep: bool) -> "_native.OperatorC":
+    def c_struct(self, dim: int, sweep: int) -> "_native.OperatorC":
         """The operator as the C ABI's ``lgc_operator`` (device pointers of tensors this object keeps alive), cached per
         embedding width because the scratch buffers are per width."""
         import ctypes
@@ -366,13 +377,13 @@ class Operator:
                 c.tiles[i] = _native.TileClassC(_native.ptr(tc.order), _native.ptr(tc.meta), _native.ptr(tc.slab), tc.n_tiles,
                                                 tc.width)
             c.n_tile_classes = len(self.tiles)
-        if sweep:
-            sw = self.sweep
+        if sweep:                                   # 4 or 2 = lgc_sweep_ok's answer for this table
+            sw = self.sweep_plan(int(sweep) if int(sweep) in (2, 4) else 4)
             sc = _native.SweepArraysC(_native.ptr(sw.slabs), _native.ptr(sw.wave_slab_ptr), _native.ptr(sw.wave_npieces),
                                       _native.ptr(sw.piece_slot), _native.ptr(sw.multi) if sw.multi.size(0) else None,
                                       _native.ptr(sw.multi_wide) if sw.multi_wide.size(0) else None,
                                       _native.ptr(sw.partials(dim)), sw.dims["n_waves"], sw.dims["row_cap"], sw.multi.size(0),
-                                      sw.multi_wide.size(0), 0)
+                                      sw.multi_wide.size(0), sw.dims["groups"])
             c.sweep = ctypes.pointer(sc)
             keep.append(sc)
         self._c_structs[key] = keep
@@ -394,7 +405,9 @@ class Operator:
         if not lib.lgc_dim_ok(dim):
             raise _native.NativeLibraryError(f"embedding width {dim} is not supported by the HIP kernels")
         table_rows = min(x.size(0), out.size(0))
-        sweep = self.sweep_cols is not None and bool(lib.lgc_sweep_ok(dim, table_rows, x.stride(0)))
+        sweep = int(lib.lgc_sweep_ok(dim, table_rows, x.stride(0))) if self.sweep_cols is not None else 0
+        if sweep == 2 and not SWEEP_WIDE:
+            sweep = 0
         c = self.c_struct(dim, sweep)
         with torch.cuda.device(x.device):
             code = lib.lgc_apply(ctypes.byref(c), table_rows, _native.ptr(x), x.stride(0), _native.ptr(out), out.stride(0),

@@ -175,7 +175,7 @@ int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries,
  *   lgc_sweep_plan_create  rows [row_begin, row_end) of the CSR; returns NULL and sets *code on error
  *   lgc_sweep_plan_dims    sizes of the arrays below
  *   lgc_sweep_plan_export  copies them into caller-provided HOST buffers:
- *       slabs uint32 [n_slabs * 256], wave_slab_ptr int32 [n_waves + 1], wave_npieces int32 [n_waves],
+ *       slabs uint32 [n_slabs * 64 * groups], wave_slab_ptr int32 [n_waves + 1], wave_npieces int32 [n_waves],
  *       piece_slot int32 [n_waves * row_cap], multi lgc_multi_row [n_rows]
  *   lgc_sweep_plan_free
  * The caller uploads the arrays and passes device pointers to lgc_spmm_sweep, with a scratch `partials` of
@@ -193,10 +193,13 @@ typedef struct lgc_sweep_cfg {
                                       exceed one XCD's LDS); 1: the bands run one after the other on the whole chip
                                       (waves_per_band_round = all wavefronts of the chip, normally one round): a band then
                                       fits the Infinity Cache, so re-fetches by other XCDs are on-die                    */
+    int32_t groups;                /* entries per step = table rows a wavefront gathers per instruction: 4 (or 0) for tables
+                                      of 61..64 columns (a 16-lane group per row, 1 KiB slabs), 2 for 68..96 columns (two
+                                      DPP rows per row, 512-byte slabs)                                                   */
 } lgc_sweep_cfg;
 
 typedef struct lgc_sweep_dims {
-    int32_t n_bands, rounds, row_cap, piece_cap, n_rows, reserved;
+    int32_t n_bands, rounds, row_cap, piece_cap, n_rows, groups;
     int64_t n_waves, n_slabs, n_slots, n_entries, n_steps, n_padding;
 } lgc_sweep_dims;
 
@@ -213,7 +216,7 @@ void lgc_sweep_plan_free(lgc_sweep_plan *plan);
 int lgc_sweep_ok(int32_t dim, int64_t table_rows, int64_t x_stride);
 
 int lgc_spmm_sweep(const uint32_t *slabs, const int32_t *wave_slab_ptr, const int32_t *wave_npieces,
-                   const int32_t *piece_slot, int64_t n_waves, int32_t row_cap, const lgc_multi_row *multi,
+                   const int32_t *piece_slot, int64_t n_waves, int32_t row_cap, int32_t groups, const lgc_multi_row *multi,
                    int32_t n_rows, const lgc_multi_row *multi_wide, int32_t n_wide, float *partials, int64_t table_rows, const float *x, int64_t x_stride, float *y,
                    int64_t y_stride, const float *r, int64_t r_stride, float a, float b, int32_t dim, void *stream);
 
@@ -247,7 +250,8 @@ typedef struct lgc_sweep_arrays {
     const lgc_multi_row *multi, *multi_wide;
     float   *partials;           /* [n_slots, dim] scratch            */
     int64_t  n_waves;
-    int32_t  row_cap, n_rows, n_wide, reserved;
+    int32_t  row_cap, n_rows, n_wide;
+    int32_t  groups;             /* 4 (or 0): plan for 61..64 columns; 2: plan for 68..96 columns */
 } lgc_sweep_arrays;
 
 typedef struct lgc_operator {

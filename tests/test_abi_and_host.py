@@ -354,7 +354,8 @@ def test_saved_graph_validation_rejects_tampered_tensors():
 # ----------------------------------------------------------------------------------------------
 def _decode_sweep(dims, arr, row_cap):
     """slot -> [(col, value bits)] in list order, checking the step invariants on the way."""
-    slabs = arr["slabs"].numpy().view(np.uint32).reshape(-1, 64, 4)
+    groups = dims["groups"]
+    slabs = arr["slabs"].numpy().view(np.uint32).reshape(-1, 16 * groups, 4)
     wsp, wnp = arr["wave_slab_ptr"].numpy(), arr["wave_npieces"].numpy()
     ps = arr["piece_slot"].numpy().reshape(-1, row_cap)
     out = {}
@@ -363,7 +364,7 @@ def _decode_sweep(dims, arr, row_cap):
         for sb in range(wsp[w], wsp[w + 1]):
             for s in range(32):
                 used = set()
-                for grp in range(4):
+                for grp in range(groups):
                     x, v = int(slabs[sb, 16 * grp + (s >> 1), 2 * (s & 1)]), int(slabs[sb, 16 * grp + (s >> 1), 2 * (s & 1) + 1])
                     col, pc = x & 0xFFFFFF, x >> 24
                     if col == 0xFFFFFF:                                  # padding: dummy accumulator, value 0
@@ -378,7 +379,8 @@ def _decode_sweep(dims, arr, row_cap):
 @pytest.mark.parametrize("cfg", [dict(n_bands=8, waves_per_band_round=16, row_cap=39, piece_cap=64, lookahead=32),
                                  dict(n_bands=3, waves_per_band_round=4, row_cap=7, piece_cap=5, lookahead=4),
                                  dict(n_bands=1, waves_per_band_round=8, row_cap=200, piece_cap=1000, lookahead=64),
-                                 dict(n_bands=4, waves_per_band_round=64, row_cap=78, piece_cap=64, lookahead=64, sequential=1)])
+                                 dict(n_bands=4, waves_per_band_round=64, row_cap=78, piece_cap=64, lookahead=64, sequential=1),
+                                 dict(n_bands=8, waves_per_band_round=16, row_cap=51, piece_cap=64, lookahead=64, groups=2)])
 def test_sweep_plan_holds_every_entry_once_in_conflict_free_steps(cfg):
     from gnn_ecommerce_amd.graph import sweep_plan_host
     g = synth.make_bipartite(3000, 120, 26000, seed=4)
@@ -409,7 +411,8 @@ def test_sweep_plan_holds_every_entry_once_in_conflict_free_steps(cfg):
             prev_hi = cols[-1]
         total += len(mine)
     assert total == 26000
-    assert dims["n_padding"] == 4 * dims["n_steps"] - 26000
+    assert dims["groups"] == (cfg.get("groups") or 4)
+    assert dims["n_padding"] == dims["groups"] * dims["n_steps"] - 26000
 
 
 def test_sweep_plan_argument_errors():
@@ -421,7 +424,7 @@ def test_sweep_plan_argument_errors():
 
     def create(lo=0, hi=8, **kw):
         cfg = _native.SweepCfg(**{**dict(n_bands=8, waves_per_band_round=16, row_cap=39, piece_cap=64, lookahead=32,
-                                         sequential=0), **kw})
+                                         sequential=0, groups=4), **kw})
         h = lib.lgc_sweep_plan_create(rowptr.data_ptr(), entries.data_ptr(), 0, 2, lo, hi, ct.byref(cfg), ct.byref(code))
         if h:
             lib.lgc_sweep_plan_free(h)
@@ -430,13 +433,16 @@ def test_sweep_plan_argument_errors():
     assert create(hi=4) == (False, -1)                     # column 5 outside [0, 4)
     assert create(waves_per_band_round=6)[0] is False and create(row_cap=0)[0] is False and create(row_cap=255)[0] is False
     assert create(n_bands=0)[0] is False and create(lookahead=2)[0] is False and create(piece_cap=0)[0] is False
-    assert lib.lgc_sweep_ok(64, 1_693_929, 64) == 1 and lib.lgc_sweep_ok(61, 1000, 64) == 1
-    assert lib.lgc_sweep_ok(90, 1000, 96) == 0 and lib.lgc_sweep_ok(64, 1 << 24, 64) == 0 and lib.lgc_sweep_ok(64, 1000, 32) == 0
+    assert create(groups=3)[0] is False and create(groups=2)[0] is True
+    assert lib.lgc_sweep_ok(64, 1_693_929, 64) == 4 and lib.lgc_sweep_ok(61, 1000, 64) == 4      # entries per step
+    assert lib.lgc_sweep_ok(90, 1000, 96) == 2 and lib.lgc_sweep_ok(80, 1000, 80) == 2 and lib.lgc_sweep_ok(96, 10, 96) == 2
+    assert lib.lgc_sweep_ok(100, 1000, 100) == 0 and lib.lgc_sweep_ok(66, 1000, 66) == 0
+    assert lib.lgc_sweep_ok(64, 1 << 24, 64) == 0 and lib.lgc_sweep_ok(64, 1000, 32) == 0
     one = ct.c_void_p(256)
-    assert lib.lgc_spmm_sweep(one, one, one, one, 6, 78, one, 4, None, 0, one, 1000, one, 64, ct.c_void_p(512), 64, None, 0,
+    assert lib.lgc_spmm_sweep(one, one, one, one, 6, 78, 4, one, 4, None, 0, one, 1000, one, 64, ct.c_void_p(512), 64, None, 0,
                               1.0, 0.0, 64, None) == -1                              # waves not a multiple of 4
-    assert lib.lgc_spmm_sweep(one, one, one, one, 8, 78, one, 4, None, 0, one, 1000, one, 64, ct.c_void_p(512), 64, None, 0,
-                              1.0, 0.0, 90, None) == -2                              # width outside 61..64
+    assert lib.lgc_spmm_sweep(one, one, one, one, 8, 78, 4, one, 4, None, 0, one, 1000, one, 64, ct.c_void_p(512), 64, None, 0,
+                              1.0, 0.0, 90, None) == -2                              # a 4-entry plan on a 90-wide table
 
 
 @pytest.mark.gpu

@@ -621,7 +621,7 @@ def test_tampered_saved_graph_is_refused_at_load(device, tmp_path):
     PropGraph.load(path, device)
 
 
-@pytest.mark.parametrize("dim", [64, 61])
+@pytest.mark.parametrize("dim", [64, 61, 90, 80, 96, 68])
 def test_band_sweep_matches_the_oracle_and_the_chunked_path(device, dim, monkeypatch):
     """lgc_spmm_sweep (LDS accumulators per (row, band), column-sorted sums, fixed-order combine) on the item half of a
     bipartite graph, forced on at a size where 'auto' would not pick it: vs the oracle hop (1e-5, norm-wise) and vs the
@@ -636,13 +636,16 @@ def test_band_sweep_matches_the_oracle_and_the_chunked_path(device, dim, monkeyp
     want = oracle.lgconv(x, ei, ew)
     xd, rd = x.to(device), r.to(device)
     monkeypatch.setattr(G, "USE_SWEEP", "1")
-    for cfg in (dict(waves_per_band_round=8, row_cap=20, piece_cap=16), dict(waves_per_band_round=4, row_cap=78)):
+    groups = 4 if dim <= 64 else 2
+    for cfg in (dict(waves_per_band_round=8, row_cap=20, piece_cap=16), dict(waves_per_band_round=4, row_cap=78 if dim <= 64 else 51)):
         monkeypatch.setattr(G, "SWEEP_CFG", dict(G.SWEEP_CFG, **cfg))
+        monkeypatch.setattr(G, "SWEEP_CFG_WIDE", dict(G.SWEEP_CFG_WIDE, **cfg))
         sw = Operator.build(n, op.rowptr, op.entries, nu, n, 32, 256, sweep_cols=(0, nu))
         assert sw.sweep_cols == (0, nu)
         y = torch.full((n, dim), float("nan"), device=device)
         sw.apply(xd, y)
-        assert sw._sweep is not None and sw._sweep.dims["n_entries"] == g.nnz // 2
+        assert list(sw._sweep) == [groups] and sw._sweep[groups].dims["n_entries"] == g.nnz // 2
+        assert sw._sweep[groups].dims["groups"] == groups
         got = y[nu:].cpu()
         assert rel_fro(got, want[nu:]) <= TOL and worst_row_rel(got, want[nu:]) <= TOL
         assert torch.isnan(y[:nu]).all()                                   # only the rows of the plan are written
@@ -664,10 +667,10 @@ def test_band_sweep_matches_the_oracle_and_the_chunked_path(device, dim, monkeyp
     chunked.apply(xd, yc)
     assert rel_fro(y[nu:].cpu(), yc[nu:].cpu()) <= 1e-6
     # a width the sweep does not take falls back to the chunked path of the same operator
-    x90 = synth.xavier_table(n, 90, 5, device)
-    y90 = torch.empty_like(x90)
-    sw.apply(x90, y90)
-    assert rel_fro(y90[nu:].cpu(), oracle.lgconv(x90.cpu(), ei, ew)[nu:]) <= TOL
+    x100 = synth.xavier_table(n, 100, 5, device)
+    y100 = torch.empty_like(x100)
+    sw.apply(x100, y100)
+    assert rel_fro(y100[nu:].cpu(), oracle.lgconv(x100.cpu(), ei, ew)[nu:]) <= TOL
 
 
 @pytest.mark.parametrize("rows,cols,k", [(1, 54571, 20), (7, 1000, 5), (3, 300, 256), (5, 64, 64), (2, 5000, 1)])

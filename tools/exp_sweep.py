@@ -54,7 +54,7 @@ def main():
         t0 = time.perf_counter()
         sw = Operator.build(n, op.rowptr, op.entries, nu, n, 32, 256, sweep_cols=(0, nu))
         assert sw.sweep_cols is not None
-        sw._sweep = SweepPlan(op.rowptr, op.entries, nu, n, 0, nu, cfg)
+        sw._sweep[cfg.get('groups', 4)] = SweepPlan(op.rowptr, op.entries, nu, n, 0, nu, cfg)
         torch.cuda.synchronize()
         t_plan = time.perf_counter() - t0
         y = torch.zeros_like(x)
@@ -64,10 +64,10 @@ def main():
         fro = ((a - b).norm() / b.norm()).item()
         worst = ((a - b).norm(dim=1) / b.norm(dim=1)).max().item()
         t = timed(lambda: sw.apply(x, y, a=0.5, r=r, b=0.25))
-        d = sw.sweep.dims
+        d = sw.sweep_plan(cfg.get('groups', 4)).dims
         print(f"sweep {cfg}: {t:.1f} us   vs chunked: fro {fro:.2e} worst row {worst:.2e}   rounds {d['rounds']} "
               f"piece_cap {d['piece_cap']} waves {d['n_waves']} slabs {d['n_slabs']} slots {d['n_slots']} "
-              f"pad {d['n_padding'] / (4 * d['n_steps']):.3f}  plan {t_plan:.2f} s  {sw.sweep.nbytes() / 1e6:.0f} MB", flush=True)
+              f"pad {d['n_padding'] / (4 * d['n_steps']):.3f}  plan {t_plan:.2f} s  {sw.sweep_plan(cfg.get('groups', 4)).nbytes() / 1e6:.0f} MB", flush=True)
         del sw, y
 
 

@@ -30,7 +30,7 @@ def main():
         o = Operator.build(n, op.rowptr, op.entries, nu, n, 32, 256)
     else:
         o = Operator.build(n, op.rowptr, op.entries, nu, n, 32, 256, sweep_cols=(0, nu))
-        o._sweep = SweepPlan(op.rowptr, op.entries, nu, n, 0, nu, cfg)
+        o._sweep[cfg.get('groups', 4)] = SweepPlan(op.rowptr, op.entries, nu, n, 0, nu, cfg)
     for _ in range(iters):
         o.apply(x, y)
     torch.cuda.synchronize()
