@@ -121,7 +121,7 @@ def main():
     def chunks(xx, yy):
         _native.check(lib.lgc_spmm(rowptr.data_ptr(), entries.data_ptr(), 0, 0, 32, plan_long.chunks.data_ptr(),
                                    plan_long.n_chunks, plan_long.multi.data_ptr() if plan_long.n_multi else None,
-                                   plan_long.n_multi, partials.data_ptr(), None, 0, xx.size(0), xx.data_ptr(), xx.stride(0),
+                                   plan_long.n_multi, partials.data_ptr(), xx.size(0), xx.data_ptr(), xx.stride(0),
                                    yy.data_ptr(), yy.stride(0), None, 0, 1.0, 0.0, dim, _native.stream_of(dev)), "lgc_spmm")
 
     t_chunks = timed(lambda: chunks(x, ref))
