@@ -1257,10 +1257,13 @@ __global__ __launch_bounds__(kBlock) void k_pair_dot_bwd(const float *__restrict
 // Serving tail: multiplicative seen-mask + top-k per row, on the device
 // ----------------------------------------------------------------------------------------
 // masked[i] = score[i] * (1 - seen[i])  (src/lightgcn.py:175 -- seen items become 0, they are not removed), then the
-// k largest by (value descending, index ascending).  One workgroup per row: three radix passes (11 + 11 + 10 bits of
-// an order-preserving key, histograms in LDS) find the k-th largest key T, one pass collects everything above T plus
-// as many elements equal to T as are still needed -- lowest indices first -- and a bitonic sort orders the k winners.
-// The row is re-read from L2 (218 KB at 54,571 items), nothing but [rows, k] indices leaves the device.
+// k largest by (value descending, index ascending).  One workgroup per row.  Rows of up to 65,536 columns are read
+// ONCE: each thread keeps its 64 order-preserving keys in registers.  Short cut: the k-th largest of the 1,024
+// per-thread maxima bounds the k-th largest element from below; the few elements in or above its 11-bit bin go to a
+// list in LDS and each counts the entries ahead of it (= its output position).  Heavily tied or flat rows (list
+// longer than 512) and wider rows take the general path: three radix passes (11 + 11 + 10 bits, histograms in LDS)
+// find the k-th largest key T, one pass collects everything above T plus as many elements equal to T as are still
+// needed -- lowest indices first -- and a bitonic sort orders the k winners.  Nothing but [rows, k] leaves the device.
 constexpr int kTopkMax = 256;
 constexpr int kTopkBlock = 1024;   // 16 wavefronts on one row: a single-row request is latency-bound on one CU
 
@@ -1269,6 +1272,22 @@ __device__ __forceinline__ uint32_t order_key(float v) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);        // ascending with the value; +NaN above +inf like torch.topk
 }
 
+constexpr int kTopkRegs = 64;      // keys a thread can hold: rows up to kTopkRegs * kTopkBlock columns are read once
+constexpr int kTopkCopies = 4;     // histogram copies (lane & 3), one bank apart: scores crowd into a few exponent bins
+constexpr int kTopkHistStride = 2049;
+constexpr int kTopkShort = 512;    // longest candidate list the short cut ranks by counting
+
+// REGS: the row's masked keys live in registers (one read of the row, all passes on registers); otherwise every pass
+// streams the row again (rows wider than kTopkRegs * kTopkBlock columns).
+#ifdef LGC_TOPK_TRACE   // debug builds (tools/topk_trace.py): phase time stamps of block 0
+__device__ unsigned long long g_topk_trace[16];
+#define LGC_TOPK_STAMP(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_topk_trace[slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define LGC_TOPK_STAMP(slot) do { } while (0)
+#endif
+
+// MASK: 0 none, 1 dense [rows, n_cols] floats, 2 per-user item lists.
+template <bool REGS, int MASK>
 __global__ __launch_bounds__(kTopkBlock) void k_mask_topk(const float *__restrict__ scores, int64_t score_stride,
                                                          const float *__restrict__ seen, int64_t seen_stride,
                                                          const int64_t *__restrict__ list_ptr,
@@ -1277,14 +1296,14 @@ __global__ __launch_bounds__(kTopkBlock) void k_mask_topk(const float *__restric
                                                          int32_t k, int64_t *__restrict__ out_index,
                                                          float *__restrict__ out_value) {
     extern __shared__ uint32_t seen_bits[];     // list form of the mask: one bit per column, built here
-    __shared__ uint32_t hist[2048];
-    __shared__ unsigned long long cand[kTopkMax];
-    __shared__ uint32_t sh_bin, sh_need, sh_count, sh_wave[kTopkBlock / kWave];
+    __shared__ uint32_t hist[kTopkCopies * kTopkHistStride];
+    __shared__ uint32_t cand_key[kTopkMax], cand_inv[kTopkMax];   // candidates: key, then ~index (lowest index wins ties)
+    __shared__ uint32_t sh_bin, sh_need, sh_count, sh_short, sh_wave[kTopkBlock / kWave];
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
     const float *srow = scores + (int64_t)blockIdx.x * score_stride;
-    const float *mrow = seen ? seen + (int64_t)blockIdx.x * seen_stride : nullptr;
-    const bool listed = list_ptr != nullptr;
-    if (listed) {   // seen items of this row's user as a bitmask in LDS: the dense [rows, n_cols] mask never exists
+    const float *mrow = MASK == 1 ? seen + (int64_t)blockIdx.x * seen_stride : nullptr;
+    LGC_TOPK_STAMP(0);
+    if (MASK == 2) {   // seen items of this row's user as a bitmask in LDS: the dense [rows, n_cols] mask never exists
         for (int b = tid; b < (n_cols + 31) / 32; b += kTopkBlock) seen_bits[b] = 0u;
         __syncthreads();
         const int64_t u = list_rows ? list_rows[blockIdx.x] : (int64_t)blockIdx.x;
@@ -1296,70 +1315,182 @@ __global__ __launch_bounds__(kTopkBlock) void k_mask_topk(const float *__restric
     }
     // score * (1 - seen) in upstream's arithmetic; the list form has seen = 1 for listed columns, 0 elsewhere
     auto masked_at = [&](float s, float m, int i) {
-        if (listed) return (seen_bits[i >> 5] >> (i & 31)) & 1u ? __fmul_rn(s, 0.0f) : s;
-        return mrow ? __fmul_rn(s, __fsub_rn(1.0f, m)) : s;
+        if (MASK == 2) return (seen_bits[i >> 5] >> (i & 31)) & 1u ? __fmul_rn(s, 0.0f) : s;
+        return MASK == 1 ? __fmul_rn(s, __fsub_rn(1.0f, m)) : s;
     };
+    // slots past the row end hold key 0, below every real key (real keys are lifted to >= 1: only the one -NaN
+    // pattern 0xFFFFFFFF moves, onto its neighbour), so the passes need no bounds test.  Loads are clamped, not
+    // predicated: no divergent control flow around them.
+    auto key_of = [&](float s, float m, int i) {
+        const uint32_t key = max(order_key(masked_at(s, m, min(i, n_cols - 1))), 1u);
+        return i < n_cols ? key : 0u;
+    };
+    uint32_t keys[REGS ? kTopkRegs : 1];
+    if (REGS) {
+        constexpr int G = 16;                         // independent loads per thread in flight: one CU, latency-bound
+#pragma unroll
+        for (int j0 = 0; j0 < kTopkRegs; j0 += G) {
+            if (j0 * kTopkBlock < n_cols) {           // block-uniform
+                float sv[G], mv[G];
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    const int i = min((j0 + j) * kTopkBlock + tid, n_cols - 1);
+                    sv[j] = srow[i];
+                    mv[j] = MASK == 1 ? mrow[i] : 0.0f;
+                }
+#pragma unroll
+                for (int j = 0; j < G; ++j) keys[j0 + j] = key_of(sv[j], mv[j], (j0 + j) * kTopkBlock + tid);
+            } else {
+#pragma unroll
+                for (int j = 0; j < G; ++j) keys[j0 + j] = 0u;
+            }
+        }
+    }
+    LGC_TOPK_STAMP(1);
+    uint32_t *my_hist = hist + (lane & (kTopkCopies - 1)) * kTopkHistStride;
+    // Walk the nb bins of hist[] down from the top until `want` elements are covered: sh_bin = the bin that crosses,
+    // sh_need = elements still wanted from it, sh_count = its population.  Thread t owns nb / 1024 bins (block scan).
+    auto find_bin = [&](int nb, uint32_t want) {
+        const int per = nb / kTopkBlock;                     // 2 or 1
+        uint32_t mine = 0;
+        for (int j = 0; j < per; ++j) mine += hist[nb - 1 - (tid * per + j)];
+        uint32_t incl = mine;                                // inclusive scan, thread 0 = highest bins
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
+        }
+        if (lane == kWave - 1) sh_wave[wv] = incl;
+        __syncthreads();
+        for (int q = 0; q < wv; ++q) incl += sh_wave[q];
+        const uint32_t before = incl - mine;
+        if (before < want && incl >= want) {                 // exactly one thread
+            uint32_t acc = before;
+            for (int j = 0; j < per; ++j) {
+                const int b = nb - 1 - (tid * per + j);
+                if (acc + hist[b] >= want) { sh_bin = (uint32_t)b; sh_need = want - acc; sh_count = hist[b]; break; }
+                acc += hist[b];
+            }
+        }
+        __syncthreads();
+    };
+    auto fold_copies = [&](int nb) {
+        for (int b = tid; b < nb; b += kTopkBlock) {
+            uint32_t c = hist[b];
+#pragma unroll
+            for (int q = 1; q < kTopkCopies; ++q) c += hist[q * kTopkHistStride + b];
+            hist[b] = c;
+        }
+        __syncthreads();
+    };
+    // Short cut (keys in registers): the k-th largest of the 1024 per-thread maxima is a lower bound of the k-th
+    // largest element, and on anything but heavily tied rows only a few dozen elements reach its 11-bit bin.  Those
+    // go to a short list in LDS and every entry counts the entries ahead of it: its count is its output position.
+    // More than kTopkShort entries (ties, flat rows): the general radix passes below do the row.
+    if (REGS) {
+        uint32_t mx = 0;
+#pragma unroll
+        for (int j = 0; j < kTopkRegs; ++j) mx = max(mx, keys[j]);
+        for (int b = tid; b < kTopkCopies * kTopkHistStride; b += kTopkBlock) hist[b] = 0;
+        if (tid == 0) sh_short = 0;
+        __syncthreads();
+        atomicAdd(&my_hist[mx >> 21], 1u);                   // a thread without a column has mx = 0: bin 0, never needed
+        __syncthreads();
+        fold_copies(2048);
+        find_bin(2048, (uint32_t)k);
+        const uint32_t low = max(sh_bin << 21, 1u);
+        uint32_t *short_key = hist, *short_inv = hist + kTopkShort;   // the histogram is free again
+#pragma unroll
+        for (int j = 0; j < kTopkRegs; ++j)
+            if (j * kTopkBlock < n_cols && keys[j] >= low) {
+                const uint32_t pos = atomicAdd(&sh_short, 1u);
+                if (pos < kTopkShort) {
+                    short_key[pos] = keys[j];
+                    short_inv[pos] = 0xFFFFFFFFu - (uint32_t)(j * kTopkBlock + tid);
+                }
+            }
+        __syncthreads();
+        LGC_TOPK_STAMP(2);
+        const uint32_t n_short = sh_short;
+        if (n_short <= kTopkShort) {
+            if (wv * kWave < (int)n_short) {                 // whole wavefronts past the list have nothing to rank
+                const uint32_t kt = tid < (int)n_short ? short_key[tid] : 0u, it = tid < (int)n_short ? short_inv[tid] : 0u;
+                uint32_t ahead = 0;
+                for (uint32_t c0 = 0; c0 < n_short; c0 += 8) {   // broadcast reads, eight entries in flight; slots past
+                    uint32_t kc[8], ic[8];                       // the list end read as 0 = behind every entry
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const bool in = c0 + q < n_short;
+                        kc[q] = in ? short_key[c0 + q] : 0u;
+                        ic[q] = in ? short_inv[c0 + q] : 0u;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) ahead += (kc[q] > kt || (kc[q] == kt && ic[q] > it)) ? 1u : 0u;
+                }
+                if (tid < (int)n_short && ahead < (uint32_t)k) {
+                    const uint32_t idx = 0xFFFFFFFFu - it;
+                    out_index[(int64_t)blockIdx.x * k + ahead] = (int64_t)idx;
+                    if (out_value)
+                        out_value[(int64_t)blockIdx.x * k + ahead] =
+                            masked_at(srow[idx], MASK == 1 ? mrow[idx] : 0.0f, (int)idx);
+                }
+            }
+            LGC_TOPK_STAMP(12);
+            return;
+        }
+        __syncthreads();
+    }
     uint32_t prefix = 0, mask = 0, need = (uint32_t)k, eq_total = 0;
     const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
     for (int pass = 0; pass < 3; ++pass) {
         const int shift = shifts[pass], nb = 1 << bits[pass];
-        for (int b = tid; b < 2048; b += kTopkBlock) hist[b] = 0;
+        for (int b = tid; b < kTopkCopies * kTopkHistStride; b += kTopkBlock) hist[b] = 0;
         __syncthreads();
-        for (int base = 0; base < n_cols; base += 4 * kTopkBlock) {   // four independent loads per thread in flight
-            float sv[4], mv[4];
+        if (REGS) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int i = base + j * kTopkBlock + tid;
-                sv[j] = i < n_cols ? srow[i] : 0.0f;
-                mv[j] = (mrow && i < n_cols) ? mrow[i] : 0.0f;
-            }
+            for (int j = 0; j < kTopkRegs; ++j)
+                if (j * kTopkBlock < n_cols && (keys[j] & mask) == prefix)
+                    atomicAdd(&my_hist[(keys[j] >> shift) & (nb - 1)], 1u);
+        } else {
+            for (int base = 0; base < n_cols; base += 4 * kTopkBlock) {   // four independent loads per thread in flight
+                float sv[4], mv[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int i = base + j * kTopkBlock + tid;
-                const uint32_t key = i < n_cols ? order_key(masked_at(sv[j], mv[j], i)) : 0u;
-                if (i < n_cols && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & (nb - 1)], 1u);
-            }
-        }
-        __syncthreads();
-        if (wv == 0) {   // lane L owns `per` bins counted from the top: walk down until `need` elements are covered
-            const int per = nb / kWave;
-            uint32_t mine = 0;
-            for (int j = 0; j < per; ++j) mine += hist[nb - 1 - (lane * per + j)];
-            uint32_t incl = mine;   // inclusive scan over lanes (lane 0 = highest bins)
-            for (int off = 1; off < kWave; off <<= 1) {
-                const uint32_t o = __shfl_up(incl, off);
-                if (lane >= off) incl += o;
-            }
-            const uint32_t before = incl - mine;
-            if (before < need && incl >= need) {     // exactly one lane
-                uint32_t acc = before;
-                for (int j = 0; j < per; ++j) {
-                    const int b = nb - 1 - (lane * per + j);
-                    if (acc + hist[b] >= need) { sh_bin = (uint32_t)b; sh_need = need - acc; sh_count = hist[b]; break; }
-                    acc += hist[b];
+                for (int j = 0; j < 4; ++j) {
+                    const int i = min(base + j * kTopkBlock + tid, n_cols - 1);
+                    sv[j] = srow[i];
+                    mv[j] = MASK == 1 ? mrow[i] : 0.0f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = base + j * kTopkBlock + tid;
+                    const uint32_t key = key_of(sv[j], mv[j], i);
+                    if (i < n_cols && (key & mask) == prefix) atomicAdd(&my_hist[(key >> shift) & (nb - 1)], 1u);
                 }
             }
         }
         __syncthreads();
+        LGC_TOPK_STAMP(2 + 3 * pass);
+        fold_copies(nb);                               // into copy 0
+        LGC_TOPK_STAMP(3 + 3 * pass);
+        find_bin(nb, need);
         prefix |= sh_bin << shift;
         mask |= (uint32_t)(nb - 1) << shift;
         need = sh_need;
         eq_total = sh_count;
         __syncthreads();
+        LGC_TOPK_STAMP(4 + 3 * pass);
     }
     const uint32_t T = prefix, n_gt = (uint32_t)k - need;   // take all keys > T (n_gt of them) and `need` keys == T
     if (tid == 0) sh_count = 0;
-    for (int i = tid; i < kTopkMax; i += kTopkBlock) cand[i] = 0ull;
+    for (int i = tid; i < kTopkMax; i += kTopkBlock) cand_key[i] = cand_inv[i] = 0u;
     __syncthreads();
     const bool ties_cut = eq_total > need;                  // more elements equal T than fit: lowest indices win
     uint32_t eq_taken = 0;                                  // block-uniform, only used when ties_cut
-    for (int base = 0; base < n_cols; base += kTopkBlock) {
-        const int i = base + tid;
-        const uint32_t key = i < n_cols ? order_key(masked_at(srow[i], mrow ? mrow[i] : 0.0f, i)) : 0u;
-        const bool gt = i < n_cols && key > T, eq = i < n_cols && key == T;
+    auto collect = [&](int i, uint32_t key) {   // key 0 marks a slot past the row end (T >= 1 whenever k <= n_cols)
+        const bool gt = key > T, eq = key == T;
         if (gt || (eq && !ties_cut)) {
             const uint32_t pos = atomicAdd(&sh_count, 1u);
-            cand[pos] = ((unsigned long long)key << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i);
+            cand_key[pos] = key;
+            cand_inv[pos] = 0xFFFFFFFFu - (uint32_t)i;
         }
         if (ties_cut && eq_taken < need) {   // ordered by index: ballots + per-wave offsets (rare: exact ties at the cut)
             const unsigned long long bal = __ballot(eq);
@@ -1368,30 +1499,52 @@ __global__ __launch_bounds__(kTopkBlock) void k_mask_topk(const float *__restric
             uint32_t off = eq_taken, tot = 0;
             for (int q = 0; q < kTopkBlock / kWave; ++q) { if (q < wv) off += sh_wave[q]; tot += sh_wave[q]; }
             const uint32_t rank = off + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-            if (eq && rank < need)
-                cand[n_gt + rank] = ((unsigned long long)key << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i);
+            if (eq && rank < need) {
+                cand_key[n_gt + rank] = key;
+                cand_inv[n_gt + rank] = 0xFFFFFFFFu - (uint32_t)i;
+            }
             eq_taken += tot;
             __syncthreads();
         }
+    };
+    if (REGS) {
+#pragma unroll
+        for (int j = 0; j < kTopkRegs; ++j)
+            if (j * kTopkBlock < n_cols) collect(j * kTopkBlock + tid, keys[j]);   // block-uniform condition
+    } else {
+        for (int base = 0; base < n_cols; base += kTopkBlock) {
+            const int i = base + tid;
+            const int ic = min(i, n_cols - 1);
+            collect(i, key_of(srow[ic], MASK == 1 ? mrow[ic] : 0.0f, i));
+        }
     }
     __syncthreads();
-    // bitonic sort, descending, of the kTopkMax candidate slots (unused slots are 0 = below every real key)
-    for (int size = 2; size <= kTopkMax; size <<= 1) {
+    LGC_TOPK_STAMP(11);
+    // bitonic sort, descending, of the first n_sort >= k candidate slots (unused slots are 0 = below every real key)
+    int n_sort = 2;
+    while (n_sort < k) n_sort <<= 1;
+    for (int size = 2; size <= n_sort; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             const int a = tid, b = tid ^ stride;
-            if (a < kTopkMax && b > a) {
+            if (a < n_sort && b > a) {
                 const bool desc = (a & size) == 0;
-                const unsigned long long x = cand[a], y = cand[b];
-                if (desc ? x < y : x > y) { cand[a] = y; cand[b] = x; }
+                const uint32_t xk = cand_key[a], yk = cand_key[b], xi = cand_inv[a], yi = cand_inv[b];
+                const bool x_lt_y = xk < yk || (xk == yk && xi < yi);
+                const bool differ = xk != yk || xi != yi;
+                if (differ && (desc ? x_lt_y : !x_lt_y)) {
+                    cand_key[a] = yk; cand_inv[a] = yi;
+                    cand_key[b] = xk; cand_inv[b] = xi;
+                }
             }
             __syncthreads();
         }
     }
+    LGC_TOPK_STAMP(12);
     if (tid < k) {
-        const unsigned long long c = cand[tid];
-        const uint32_t idx = 0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFull);
+        const uint32_t idx = 0xFFFFFFFFu - cand_inv[tid];
         out_index[(int64_t)blockIdx.x * k + tid] = (int64_t)idx;
-        if (out_value) out_value[(int64_t)blockIdx.x * k + tid] = masked_at(srow[idx], mrow ? mrow[idx] : 0.0f, (int)idx);
+        if (out_value)
+            out_value[(int64_t)blockIdx.x * k + tid] = masked_at(srow[idx], MASK == 1 ? mrow[idx] : 0.0f, (int)idx);
     }
 }
 
@@ -2148,18 +2301,25 @@ int lgc_mask_topk(const float *scores, int64_t score_stride, const float *seen, 
         return LGC_E_INVAL;
     if (k > kTopkMax) return LGC_E_RANGE;
     const size_t lds = list_ptr ? (size_t)((n_cols + 31) / 32) * 4 : 0;
-    if (lds > 128 * 1024) return LGC_E_RANGE;             // the bitmask form holds up to 1,048,576 columns
+    if (lds > 120 * 1024) return LGC_E_RANGE;             // the bitmask form holds up to 983,040 columns
     if (n_rows == 0) return 0;
-    if (lds > 48 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mask_topk),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    const bool regs = n_cols <= kTopkRegs * kTopkBlock;
+    const int mode = list_ptr ? 2 : seen ? 1 : 0;
+    using topk_fn = void (*)(const float *, int64_t, const float *, int64_t, const int64_t *, const int64_t *,
+                             const int64_t *, int32_t, int32_t, int64_t *, float *);
+    static const topk_fn kerns[2][3] = {{k_mask_topk<false, 0>, k_mask_topk<false, 1>, k_mask_topk<false, 2>},
+                                        {k_mask_topk<true, 0>, k_mask_topk<true, 1>, k_mask_topk<true, 2>}};
+    const topk_fn kern = kerns[regs][mode];
+    if (lds > 16 * 1024) {    // static LDS (histogram copies, candidates) + the bitmask can pass the 64 KiB default
+        static bool attr_set[2] = {false, false};
+        if (!attr_set[regs]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
             if (e != hipSuccess) return (int)e;
-            attr_set = true;
+            attr_set[regs] = true;
         }
     }
-    hipLaunchKernelGGL(k_mask_topk, dim3((unsigned)n_rows), dim3(kTopkBlock), lds, as_stream(stream_), scores, score_stride, seen,
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_rows), dim3(kTopkBlock), lds, as_stream(stream_), scores, score_stride, seen,
                        seen_stride, list_ptr, list_items, list_rows, n_cols, k, out_index, out_value);
     return (int)hipGetLastError();
 }
@@ -2174,5 +2334,11 @@ int lgc_sample_triples(const int64_t *users, int64_t n, const int32_t *pos_ptr, 
                        pos_ptr, pos_items, ign_ptr, ign_items, n_users, n_items, seed, step, pos_out, neg_out, status);
     return (int)hipGetLastError();
 }
+
+#ifdef LGC_TOPK_TRACE
+int lgc_debug_topk_trace(unsigned long long *out16) {
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_topk_trace), sizeof(unsigned long long) * 16);
+}
+#endif
 
 }  // extern "C"

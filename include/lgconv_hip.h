@@ -317,7 +317,7 @@ int lgc_pair_dot_backward(const float *grad_scores, const float *emb, int64_t st
  *           (index_select on the sparse purchase matrix + to_dense, lightgcn_handler.py:88);
  *   lists   list_ptr int64 [n_users + 1], list_items int64 (a CSR of the purchase matrix, seen = 1 for listed
  *           columns), list_rows int64 [n_rows] = the user of each score row (NULL: row r is user r): the kernel
- *           builds a bit per column in LDS, the dense mask never exists (n_cols <= 1,048,576).
+ *           builds a bit per column in LDS, the dense mask never exists (n_cols <= 983,040).
  *   scores fp32 [n_rows, n_cols] (row stride in floats), out_index int64 [n_rows, k], out_value fp32 [n_rows, k] or NULL. */
 int lgc_mask_topk(const float *scores, int64_t score_stride, const float *seen, int64_t seen_stride,
                   const int64_t *list_ptr, const int64_t *list_items, const int64_t *list_rows, int64_t n_rows,

@@ -673,7 +673,8 @@ def test_band_sweep_matches_the_oracle_and_the_chunked_path(device, dim, monkeyp
     assert rel_fro(y100[nu:].cpu(), oracle.lgconv(x100.cpu(), ei, ew)[nu:]) <= TOL
 
 
-@pytest.mark.parametrize("rows,cols,k", [(1, 54571, 20), (7, 1000, 5), (3, 300, 256), (5, 64, 64), (2, 5000, 1)])
+@pytest.mark.parametrize("rows,cols,k", [(1, 54571, 20), (7, 1000, 5), (3, 300, 256), (5, 64, 64), (2, 5000, 1),
+                                         (3, 1024, 7), (2, 1025, 3), (2, 65536, 33), (2, 70001, 20)])
 def test_mask_topk_matches_torch_and_breaks_ties_by_index(device, rows, cols, k):
     from gnn_ecommerce_amd.propagate import mask_topk
     gen = torch.Generator().manual_seed(rows * 1000 + k)
@@ -711,6 +712,29 @@ def test_mask_topk_matches_torch_and_breaks_ties_by_index(device, rows, cols, k)
     assert mask_topk(scores.to(device), torch.ones(rows, cols, device=device), k).cpu()[0].tolist() == list(range(k))
     with pytest.raises(RuntimeError):
         mask_topk(scores.to(device), None, cols + 1)
+
+
+@pytest.mark.parametrize("cols", [777, 66000])       # keys held in registers / streamed per pass
+def test_mask_topk_orders_infinities_and_signed_zeros_like_torch(device, cols):
+    from gnn_ecommerce_amd.propagate import mask_topk
+    gen = torch.Generator().manual_seed(cols)
+    scores = torch.randn(4, cols, generator=gen)
+    scores[0, 5], scores[0, 9], scores[0, 700] = float("inf"), float("-inf"), float("inf")
+    scores[1] = -scores[1].abs() - 1.0                   # all negative: seen columns (x0 -> -0.0) are the largest
+    scores[2, ::2] = -0.0
+    scores[2, 1::2] = 0.0                                # -0 and +0 tie: index order
+    scores[3] = float("-inf")
+    scores[3, 300:310] = -1e30
+    seen = torch.zeros(4, cols)
+    seen[1, 100:130] = 1.0
+    k = 40
+    masked = scores * (1 - seen)
+    got = mask_topk(scores.to(device), seen.to(device), k).cpu()
+    assert torch.equal(torch.gather(masked, 1, got), masked.topk(k, dim=-1).values)
+    assert got[0, :2].tolist() == [5, 700]
+    assert got[1, :30].tolist() == list(range(100, 130))
+    assert got[2].tolist() == list(range(k))
+    assert got[3, :10].tolist() == list(range(300, 310)) and got[3, 10:].tolist() == list(range(30))
 
 
 def test_recommendk_frame_is_upstreams_frame(device):

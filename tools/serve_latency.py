@@ -34,4 +34,22 @@ for n_users in (1, 64):
                 model.recommendK(ei, ew, g.n_users, g.n_items, seen, users, 20)
                 ts.append((time.perf_counter() - t0) * 1e3)
         out[f"users{n_users}_{'reuse' if reuse else 'recompute'}_ms"] = round(statistics.median(ts[3:]), 3)
+# the select kernel alone (HIP events): dense device mask and the list form
+from gnn_ecommerce_amd.propagate import SeenLists, mask_topk
+for rows in (1, 64, 1024):
+    sc = torch.randn(rows, g.n_items, device=dev)
+    dense = (torch.rand(rows, g.n_items, device=dev) < 0.001).float()
+    nz = torch.nonzero(dense)
+    ptr = torch.zeros(rows + 1, dtype=torch.int64, device=dev)
+    ptr[1:] = torch.cumsum(dense.sum(dim=1).long(), 0)
+    lists = SeenLists(ptr, nz[:, 1].contiguous(), torch.arange(rows, device=dev))
+    for name, m in (("dense", dense), ("lists", lists)):
+        for _ in range(3):
+            mask_topk(sc, m, 20)
+        ts = []
+        for _ in range(20):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(); mask_topk(sc, m, 20); e.record(); torch.cuda.synchronize()
+            ts.append(s.elapsed_time(e) * 1e3)
+        out[f"mask_topk_rows{rows}_{name}_us"] = round(statistics.median(ts), 1)
 print(json.dumps(out))
