@@ -228,7 +228,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_note,
                          "kernel": "one hop = one LGConv layer: item step k_sweep + k_sweep_combine, user step "
-                                   "k_rows_tile_dpp<8|16|32> + k_spmm_hop (rows > 32 entries)",
+                                   "k_apply_fused (one launch: tile classes 8|16|32 through the DPP row kernel + chunked rows > 32 entries)",
                          "algorithmic_bytes_per_launch": bmin, "launch_ms": hop_mean_s * 1e3,
                          "launches_timed": len(hop_ms)},
         }

@@ -17,7 +17,7 @@ import torch
 LIB_NAME = "liblgconv_hip.so"
 # LGCN_LIB_PATH selects another build of the SAME library (A/B kernel experiments); never a fallback.
 LIB_PATH = os.environ.get("LGCN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", LIB_NAME)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # status bits (include/lgconv_hip.h)
 ST_INDEX_OOB = 1
@@ -26,7 +26,7 @@ ST_SAMPLER_EXHAUSTED = 2
 class SweepCfg(Structure):
     """lgc_sweep_cfg"""
     _fields_ = [("n_bands", c_int32), ("waves_per_band_round", c_int32), ("row_cap", c_int32), ("piece_cap", c_int32),
-                ("lookahead", c_int32), ("sequential", c_int32), ("groups", c_int32)]
+                ("lookahead", c_int32), ("sequential", c_int32), ("groups", c_int32), ("round_order", c_int32)]
 
 
 class SweepDims(Structure):

@@ -907,8 +907,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, DEPTH
 #undef LGC_STEP
 #undef LGC_CONSUME
 #undef LGC_ISSUE
-        if (p.trace && lane == 0 && tk < 16) p.trace[(int64_t)w * 16 + tk++] = __builtin_amdgcn_s_memrealtime();
+        if (p.trace && lane == 0 && tk < 15) p.trace[(int64_t)w * 16 + tk++] = __builtin_amdgcn_s_memrealtime();
     }
+    if (p.trace && lane == 0) p.trace[(int64_t)w * 16 + 15] = __builtin_amdgcn_s_memrealtime();   // end of the last slab
     // write my pieces to their partial slots: lane group g takes pieces g, g + 4, ...
     const int32_t *slots = p.piece_slot + (int64_t)w * p.row_cap;
     for (int pc = g; pc < npieces; pc += 4) {
@@ -1743,9 +1744,18 @@ int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry 
     for (int b = 0; b < NB; ++b) {
         auto &v = by_band[(size_t)b];
         std::stable_sort(v.begin(), v.end(), [&](int32_t a, int32_t c) { return pieces[(size_t)a].count > pieces[(size_t)c].count; });
+        const bool by_weight = cfg.round_order == 1;
+        const size_t per_round = ((v.size() + (size_t)rounds - 1) / (size_t)rounds);
         for (size_t k = 0; k < v.size(); ++k) {
-            const int64_t lap = (int64_t)(k / (size_t)U), pos = (int64_t)(k % (size_t)U);
-            const int64_t u = (lap & 1) ? (U - 1 - pos) : pos;
+            int64_t u;
+            if (by_weight) {   // heaviest pieces fill round 0, the next round 1, ...: serpentine inside the round
+                const int64_t rr = (int64_t)(k / per_round), kk = (int64_t)(k % per_round);
+                const int64_t lap = kk / WPBR, pos = kk % WPBR;
+                u = rr * WPBR + ((lap & 1) ? (WPBR - 1 - pos) : pos);
+            } else {
+                const int64_t lap = (int64_t)(k / (size_t)U), pos = (int64_t)(k % (size_t)U);
+                u = (lap & 1) ? (U - 1 - pos) : pos;
+            }
             const int64_t r = u / WPBR, j = u % WPBR;
             // bands side by side: block = (r, j / 4, band), band = block % NB (one band per XCD, all bands at once);
             // bands one after the other: all waves of band b precede those of band b + 1 (dispatch order = time order)
@@ -2057,7 +2067,8 @@ lgc_sweep_plan *lgc_sweep_plan_create(const int32_t *rowptr_host, const lgc_entr
     if (rowptr_host && (entries_host || rowptr_host[row_end] == rowptr_host[row_begin]) && cfg && row_begin >= 0 &&
         row_end >= row_begin && col_lo >= 0 && col_hi > col_lo && col_hi <= 0xFFFFFF && cfg->n_bands >= 1 &&
         cfg->n_bands <= 64 && cfg->waves_per_band_round >= 4 && cfg->waves_per_band_round % 4 == 0 && cfg->row_cap >= 1 &&
-        cfg->row_cap <= 254 && cfg->piece_cap >= 1 && cfg->lookahead >= 4 && (cfg->groups == 0 || cfg->groups == 2 || cfg->groups == 4)) {
+        cfg->row_cap <= 254 && cfg->piece_cap >= 1 && cfg->lookahead >= 4 && (cfg->groups == 0 || cfg->groups == 2 || cfg->groups == 4) &&
+        (cfg->round_order == 0 || cfg->round_order == 1)) {
         pl = new (std::nothrow) lgc_sweep_plan();
         if (pl) {
             try {

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LGC_ABI_VERSION 6
+#define LGC_ABI_VERSION 7
 
 /* argument errors (negative return values) */
 #define LGC_E_INVAL      (-1)  /* null pointer, negative size, bad flag                    */
@@ -184,8 +184,8 @@ int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries,
  */
 typedef struct lgc_sweep_cfg {
     int32_t n_bands;               /* 8: one band per XCD (blockIdx % 8)                               */
-    int32_t waves_per_band_round;  /* 512: 32 CUs x 16 wavefronts                                      */
-    int32_t row_cap;               /* 39: accumulators per wavefront (16 x 40 rows x 256 B = 160 KiB)  */
+    int32_t waves_per_band_round;  /* 256: 32 CUs x 8 wavefronts                                       */
+    int32_t row_cap;               /* 78: accumulators per wavefront (8 x 79 rows x 256 B = 158 KiB; 51 for 68..96 columns) */
     int32_t piece_cap;             /* 64: longest run of one row's entries inside one wavefront's list; raised in
                                       steps of 16 (up to 4x) while that saves a whole round                */
     int32_t lookahead;             /* 64: how far the step builder looks for an entry of another piece  */
@@ -196,6 +196,12 @@ typedef struct lgc_sweep_cfg {
     int32_t groups;                /* entries per step = table rows a wavefront gathers per instruction: 4 (or 0) for tables
                                       of 61..64 columns (a 16-lane group per row, 1 KiB slabs), 2 for 68..96 columns (two
                                       DPP rows per row, 512-byte slabs)                                                   */
+    int32_t round_order;           /* which pieces of a band share a round.  0: every round gets the same mix (pieces dealt
+                                      heaviest-first over all wavefronts of the band); 1: the heaviest pieces fill round 0,
+                                      the next round 1, ... (dealt heaviest-first inside the round).  A column's table row
+                                      is fetched once per round that holds a piece using it, so grouping the long pieces
+                                      leaves the later rounds touching few columns: 576 -> 551 us per hop on the
+                                      1.6 M x 54 k graph                                                                  */
 } lgc_sweep_cfg;
 
 typedef struct lgc_sweep_dims {

@@ -380,7 +380,9 @@ def _decode_sweep(dims, arr, row_cap):
                                  dict(n_bands=3, waves_per_band_round=4, row_cap=7, piece_cap=5, lookahead=4),
                                  dict(n_bands=1, waves_per_band_round=8, row_cap=200, piece_cap=1000, lookahead=64),
                                  dict(n_bands=4, waves_per_band_round=64, row_cap=78, piece_cap=64, lookahead=64, sequential=1),
-                                 dict(n_bands=8, waves_per_band_round=16, row_cap=51, piece_cap=64, lookahead=64, groups=2)])
+                                 dict(n_bands=8, waves_per_band_round=16, row_cap=51, piece_cap=64, lookahead=64, groups=2),
+                                 dict(n_bands=8, waves_per_band_round=4, row_cap=3, piece_cap=64, lookahead=32, round_order=1),
+                                 dict(n_bands=3, waves_per_band_round=4, row_cap=7, piece_cap=5, lookahead=4, round_order=1)])
 def test_sweep_plan_holds_every_entry_once_in_conflict_free_steps(cfg):
     from gnn_ecommerce_amd.graph import sweep_plan_host
     g = synth.make_bipartite(3000, 120, 26000, seed=4)
@@ -413,6 +415,19 @@ def test_sweep_plan_holds_every_entry_once_in_conflict_free_steps(cfg):
     assert total == 26000
     assert dims["groups"] == (cfg.get("groups") or 4)
     assert dims["n_padding"] == dims["groups"] * dims["n_steps"] - 26000
+    if cfg.get("round_order") == 1 and dims["rounds"] > 1:
+        # rounds by weight: inside a band no piece of a later round is longer than a piece of an earlier round
+        wnp, ps = arr["wave_npieces"].numpy(), arr["piece_slot"].numpy().reshape(dims["n_waves"], cfg["row_cap"])
+        nb, wpbr = cfg["n_bands"], cfg["waves_per_band_round"]
+        for b in range(nb):
+            lo_prev = None
+            for r in range(dims["rounds"]):
+                lens = [len(got[int(ps[w, k])]) for w in range(dims["n_waves"])
+                        if (w // 4) % nb == b and (w // 4) // nb // (wpbr // 4) == r for k in range(wnp[w])]
+                if not lens:
+                    continue
+                assert lo_prev is None or max(lens) <= lo_prev
+                lo_prev = min(lens)
 
 
 def test_sweep_plan_argument_errors():
@@ -434,6 +449,7 @@ def test_sweep_plan_argument_errors():
     assert create(waves_per_band_round=6)[0] is False and create(row_cap=0)[0] is False and create(row_cap=255)[0] is False
     assert create(n_bands=0)[0] is False and create(lookahead=2)[0] is False and create(piece_cap=0)[0] is False
     assert create(groups=3)[0] is False and create(groups=2)[0] is True
+    assert create(round_order=2)[0] is False and create(round_order=1)[0] is True
     assert lib.lgc_sweep_ok(64, 1_693_929, 64) == 4 and lib.lgc_sweep_ok(61, 1000, 64) == 4      # entries per step
     assert lib.lgc_sweep_ok(90, 1000, 96) == 2 and lib.lgc_sweep_ok(80, 1000, 80) == 2 and lib.lgc_sweep_ok(96, 10, 96) == 2
     assert lib.lgc_sweep_ok(100, 1000, 100) == 0 and lib.lgc_sweep_ok(66, 1000, 66) == 0

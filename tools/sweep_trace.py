@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: how far apart do the wavefronts of one band drift during a sweep round?  Every wave stamps
-s_memrealtime (100 MHz) at its start and after each slab (LGCN_SWEEP_TRACE = address of a [n_waves, 16] u64 buffer).
+s_memrealtime (100 MHz) at its start and after each slab (LGCN_SWEEP_TRACE = address of a [n_waves, 16] u64 buffer; slots 0..14 = start and the first 14 slabs, 15 = end).
 Prints, per round, the spread of start times and of the times at which waves finish their k-th slab."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -39,11 +39,11 @@ for r in range(rounds):
         tt = t[sel] - t0
         ns = nslab[sel]
         line = f"round {r} band {b}: start {tt[:, 0].min():6.1f}..{tt[:, 0].max():6.1f}"
-        for k in (1, 3, 5, 7):
+        for k in (1, 3, 5, 7, 11):
             ok = ns >= k
             if ok.any():
                 v = tt[ok, k]
                 line += f" | slab{k} {np.percentile(v, 5):6.1f}..{np.percentile(v, 95):6.1f} (sd {v.std():4.1f})"
-        end = np.array([tt[i, ns[i]] for i in range(len(ns))])
+        end = tt[:, 15]                                      # slot 15 = end of the wave's last slab
         line += f" | end {end.min():6.1f}..{end.max():6.1f}"
         print(line)
