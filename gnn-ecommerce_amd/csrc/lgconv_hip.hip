@@ -170,13 +170,13 @@ BuildWs carve_build_ws(void *base, int64_t n_nodes, int64_t n_edges) {
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, nul, nul, nul, nul, (int)n_edges, 0,
                                              end_bit_for(n_nodes), (hipStream_t)0);
     size_t arr = align_up((size_t)n_edges * 4, 256);
-    char *p = reinterpret_cast<char *>(base);
+    const uintptr_t p = reinterpret_cast<uintptr_t>(base);   // integer arithmetic: base is null when only sizing
     ws.keys_in = reinterpret_cast<int32_t *>(p);
     ws.keys_out = reinterpret_cast<int32_t *>(p + arr);
     ws.ids_in = reinterpret_cast<int32_t *>(p + 2 * arr);
     ws.ids_out = reinterpret_cast<int32_t *>(p + 3 * arr);
     ws.w_sorted = reinterpret_cast<float *>(p);  // reuses keys_in after the sort
-    ws.cub = p + 4 * arr;
+    ws.cub = reinterpret_cast<void *>(p + 4 * arr);
     ws.cub_bytes = align_up(cub_bytes, 256);
     ws.total = 4 * arr + ws.cub_bytes + 256;
     return ws;
