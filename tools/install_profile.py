@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Copy one profiles/collect.sh run from gpurun_out/prof_<tag>/ into profiles/ (replacing the previous set of the same
+round) and stamp profiles/traffic.json -- only if the PMC run's kernel-source hash is the current source's.
+    python tools/install_profile.py <tag> [<old tag to remove>]"""
+import glob, json, os, shutil, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+
+tag = sys.argv[1]
+old = sys.argv[2] if len(sys.argv) > 2 else None
+src = f"gpurun_out/prof_{tag}"
+d = json.load(open(f"{src}/summary.json"))
+h = bench.kernel_source_hash()
+assert d["traffic_json"]["kernel_source_sha256"] == h, ("profile is of another source", d["traffic_json"], h)
+shutil.copy(f"{src}/summary.json", f"profiles/{tag}_pmc_summary.json")
+shutil.copy(glob.glob(f"{src}/trace/*/*kernel_stats.csv")[0], f"profiles/{tag}_kernel_stats.csv")
+for name, dst in ((f"gpurun_out/bench_{tag}.json", f"profiles/{tag}_bench.json"),
+                  (f"gpurun_out/bench_{tag}_d90.json", f"profiles/{tag}_bench_configs2_d90_k5.json")):
+    if os.path.isfile(name):
+        open(dst, "w").write(open(name).read().strip().splitlines()[-1] + "\n")
+t = json.load(open("profiles/traffic.json"))
+t.update(source=f"profiles/{tag}_pmc_summary.json", kernel_source_sha256=h, cosmetics_d64=d["traffic_json"]["hbm_bytes_per_hop"])
+json.dump(t, open("profiles/traffic.json", "w"), indent=1)
+if old:
+    for f in glob.glob(f"profiles/{old}_*"):
+        os.remove(f)
+b = json.loads(open(f"profiles/{tag}_bench.json").read())
+print("installed", tag, "hop", b["roofline"]["launch_ms"], "frac", b["roofline"]["frac"], "traffic", t["cosmetics_d64"])
