@@ -102,6 +102,15 @@ def cpu_baseline(graph, layers, dim, threads=0):
     return out
 
 
+def workload_name(args, world: int) -> str:
+    """Which BASELINE.json configuration the arguments describe."""
+    if args.config != "cosmetics":
+        return "configs[0]-sized plumbing graph"
+    if world > 1:
+        return "configs[3]"
+    return "configs[2]" if (args.layers, args.dim) == (5, 90) else "configs[1]"
+
+
 def kernel_source_hash() -> str:
     """sha256 over the files that decide which bytes a hop moves: the kernels and the work plans."""
     import hashlib
@@ -220,7 +229,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"configs[1]: {graph.n_users} users x {graph.n_items} items, "
+            "config": {"workload": f"{workload_name(args, world)}: {graph.n_users} users x {graph.n_items} items, "
                                    f"{nnz} directed edges, {args.layers} LGConv layers, emb_dim {args.dim}, "
                                    "get_embedding (K hops + fused layer sum)",
                        "parallelism": parallelism, "seed": SEED,

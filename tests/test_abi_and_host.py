@@ -430,6 +430,53 @@ def test_sweep_plan_holds_every_entry_once_in_conflict_free_steps(cfg):
                 lo_prev = min(lens)
 
 
+def test_sweep_plan_on_random_small_operators():
+    """Property test (hypothesis): any CSR slice -- empty rows, rows living in one band, duplicate columns, a single
+    column, more bands than columns -- and any legal planner configuration: every entry lands in exactly one slot of
+    its own row, steps are conflict-free, slots of a row are contiguous."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    from gnn_ecommerce_amd.graph import sweep_plan_host
+
+    @st.composite
+    def cases(draw):
+        n_rows = draw(st.integers(1, 12))
+        n_cols = draw(st.integers(1, 40))
+        lens = draw(st.lists(st.integers(0, 30), min_size=n_rows, max_size=n_rows))
+        cols = [draw(st.lists(st.integers(0, n_cols - 1), min_size=l, max_size=l)) for l in lens]
+        cfg = dict(n_bands=draw(st.sampled_from([1, 2, 3, 8])), waves_per_band_round=draw(st.sampled_from([4, 8])),
+                   row_cap=draw(st.sampled_from([1, 2, 5, 78])), piece_cap=draw(st.sampled_from([1, 3, 64])),
+                   lookahead=draw(st.sampled_from([4, 64])), sequential=draw(st.sampled_from([0, 1])),
+                   groups=draw(st.sampled_from([2, 4])), round_order=draw(st.sampled_from([0, 1])))
+        return n_cols, cols, cfg
+
+    @settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(cases())
+    def check(case):
+        n_cols, cols, cfg = case
+        n_rows = len(cols)
+        rowptr = torch.zeros(n_rows + 1, dtype=torch.int32)
+        rowptr[1:] = torch.cumsum(torch.tensor([len(c) for c in cols]), 0)
+        flat = [c for row in cols for c in row]
+        ne = len(flat)
+        entries = torch.zeros((max(ne, 1), 2), dtype=torch.int32)
+        if ne:
+            entries[:ne, 0] = torch.tensor(flat, dtype=torch.int32)
+            entries[:ne, 1] = torch.arange(1, ne + 1, dtype=torch.int32)          # value bits identify the entry
+        dims, arr = sweep_plan_host(rowptr, entries[:ne] if ne else entries[:0], 0, n_rows, 0, n_cols, cfg)
+        assert dims["n_entries"] == ne and dims["n_rows"] == n_rows
+        got = _decode_sweep(dims, arr, cfg["row_cap"])
+        multi = arr["multi"].numpy()[:n_rows]
+        seen = 0
+        for row, sb, se, _ in multi:
+            mine = sorted(e for sl in range(sb, se) for e in got.get(sl, []))
+            want = sorted((int(c), int(v)) for c, v in entries[rowptr[row]:rowptr[row + 1]].tolist())
+            assert mine == want
+            seen += len(mine)
+        assert seen == ne and sum(len(v) for v in got.values()) == ne
+        assert dims["n_padding"] == dims["groups"] * dims["n_steps"] - ne
+    check()
+
+
 def test_sweep_plan_argument_errors():
     import ctypes as ct
     lib = _native.load()
