@@ -1744,7 +1744,7 @@ int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry 
     for (int b = 0; b < NB; ++b) {
         auto &v = by_band[(size_t)b];
         std::stable_sort(v.begin(), v.end(), [&](int32_t a, int32_t c) { return pieces[(size_t)a].count > pieces[(size_t)c].count; });
-        const bool by_weight = cfg.round_order == 1;
+        const bool by_weight = cfg.round_order >= 1;
         const size_t per_round = ((v.size() + (size_t)rounds - 1) / (size_t)rounds);
         for (size_t k = 0; k < v.size(); ++k) {
             int64_t u;
@@ -1771,6 +1771,7 @@ int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry 
     std::vector<int64_t> wave_steps((size_t)n_waves, 0), wave_pad((size_t)n_waves, 0);
     pl.wave_npieces.assign((size_t)n_waves, 0);
     pl.piece_slot.assign((size_t)n_waves * CAP, 0);
+    const bool serpentine = cfg.round_order == 2 && !cfg.sequential;
     parallel_for(n_waves, [&](int64_t wlo, int64_t whi) {
         struct Item { int32_t col; float val; int32_t piece; };
         std::vector<Item> items;
@@ -1787,6 +1788,9 @@ int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry 
                     items.push_back({sorted[(size_t)(pc.begin + k)].col, sorted[(size_t)(pc.begin + k)].val, (int32_t)lp});
             }
             std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.col < b.col; });
+            // odd rounds walk their band back down: what the previous round touched last is touched first, while it
+            // is still in the Infinity Cache (and, for a few microseconds, in L2)
+            if (serpentine && (((w / 4) / NB) / (WPBR / 4)) % 2 == 1) std::reverse(items.begin(), items.end());
             done.assign(items.size(), 0);
             size_t head = 0;
             int64_t step = 0, pad = 0;
@@ -2068,7 +2072,7 @@ lgc_sweep_plan *lgc_sweep_plan_create(const int32_t *rowptr_host, const lgc_entr
         row_end >= row_begin && col_lo >= 0 && col_hi > col_lo && col_hi <= 0xFFFFFF && cfg->n_bands >= 1 &&
         cfg->n_bands <= 64 && cfg->waves_per_band_round >= 4 && cfg->waves_per_band_round % 4 == 0 && cfg->row_cap >= 1 &&
         cfg->row_cap <= 254 && cfg->piece_cap >= 1 && cfg->lookahead >= 4 && (cfg->groups == 0 || cfg->groups == 2 || cfg->groups == 4) &&
-        (cfg->round_order == 0 || cfg->round_order == 1)) {
+        cfg->round_order >= 0 && cfg->round_order <= 2) {
         pl = new (std::nothrow) lgc_sweep_plan();
         if (pl) {
             try {

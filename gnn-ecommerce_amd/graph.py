@@ -51,8 +51,9 @@ SWEEP_CFG = dict(n_bands=int(os.environ.get("LGCN_SWEEP_BANDS", "8")), waves_per
                  lookahead=int(os.environ.get("LGCN_SWEEP_LOOKAHEAD", "64")),
                  sequential=int(os.environ.get("LGCN_SWEEP_SEQUENTIAL", "0")), groups=4,
                  # rounds by piece weight: a gathered row is fetched once per round that uses it, so the long pieces
-                 # share round 0 and the later rounds touch few columns (576 -> 551 us per hop)
-                 round_order=int(os.environ.get("LGCN_SWEEP_ROUND_ORDER", "1")))
+                 # share round 0 and the later rounds touch few columns (576 -> 551 us per hop); 2 = odd rounds also walk
+                 # their band downwards, starting on the rows the previous round left in the Infinity Cache (-2 us)
+                 round_order=int(os.environ.get("LGCN_SWEEP_ROUND_ORDER", "2")))
 SWEEP_WIDE = os.environ.get("LGCN_SWEEP_WIDE", "1") == "1"
 # tables of 68..96 columns: a row takes two DPP rows, LDS rows are 96 floats -> 51 accumulators per wavefront
 SWEEP_CFG_WIDE = dict(SWEEP_CFG, row_cap=int(os.environ.get("LGCN_SWEEP_ROW_CAP_WIDE", "51")), groups=2)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LGC_ABI_VERSION 7
+#define LGC_ABI_VERSION 8
 
 /* argument errors (negative return values) */
 #define LGC_E_INVAL      (-1)  /* null pointer, negative size, bad flag                    */
@@ -201,7 +201,10 @@ typedef struct lgc_sweep_cfg {
                                       the next round 1, ... (dealt heaviest-first inside the round).  A column's table row
                                       is fetched once per round that holds a piece using it, so grouping the long pieces
                                       leaves the later rounds touching few columns: 576 -> 551 us per hop on the
-                                      1.6 M x 54 k graph                                                                  */
+                                      1.6 M x 54 k graph; 2: as 1, and the odd rounds walk their band in descending column
+                                      order (a round starts where the previous one ended, on rows still in the Infinity
+                                      Cache: another 2 us per hop).  Entries of a piece are then accumulated in
+                                      descending column order in odd rounds (still one fixed order per plan)              */
 } lgc_sweep_cfg;
 
 typedef struct lgc_sweep_dims {

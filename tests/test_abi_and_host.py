@@ -382,9 +382,11 @@ def _decode_sweep(dims, arr, row_cap):
                                  dict(n_bands=4, waves_per_band_round=64, row_cap=78, piece_cap=64, lookahead=64, sequential=1),
                                  dict(n_bands=8, waves_per_band_round=16, row_cap=51, piece_cap=64, lookahead=64, groups=2),
                                  dict(n_bands=8, waves_per_band_round=4, row_cap=3, piece_cap=64, lookahead=32, round_order=1),
-                                 dict(n_bands=3, waves_per_band_round=4, row_cap=7, piece_cap=5, lookahead=4, round_order=1)])
+                                 dict(n_bands=3, waves_per_band_round=4, row_cap=7, piece_cap=5, lookahead=4, round_order=1),
+                                 dict(n_bands=8, waves_per_band_round=4, row_cap=3, piece_cap=64, lookahead=32, round_order=2)])
 def test_sweep_plan_holds_every_entry_once_in_conflict_free_steps(cfg):
-    from gnn_ecommerce_amd.graph import sweep_plan_host
+    from gnn_ecommerce_amd.graph import SWEEP_CFG, sweep_plan_host
+    cfg = dict(cfg, round_order=cfg.get("round_order", SWEEP_CFG["round_order"]))     # the planner's default applies
     g = synth.make_bipartite(3000, 120, 26000, seed=4)
     ei, ew = g.coo()
     n, nu = g.num_nodes, g.n_users
@@ -409,13 +411,17 @@ def test_sweep_plan_holds_every_entry_once_in_conflict_free_steps(cfg):
         prev_hi = -1
         for sl in range(sb, se):                     # inside a slot: ascending columns; slots of a row: ascending ranges
             cols = [c for c, _ in got.get(sl, [])]
-            assert cols and cols == sorted(cols) and len(cols) <= dims["piece_cap"] and cols[0] >= prev_hi
+            assert cols and len(cols) <= dims["piece_cap"]
+            if cfg.get("round_order") == 2:        # odd rounds walk downwards: a slot's list is sorted one way or the other
+                assert cols == sorted(cols) or cols == sorted(cols, reverse=True)
+                cols = sorted(cols)
+            assert cols == sorted(cols) and cols[0] >= prev_hi
             prev_hi = cols[-1]
         total += len(mine)
     assert total == 26000
     assert dims["groups"] == (cfg.get("groups") or 4)
     assert dims["n_padding"] == dims["groups"] * dims["n_steps"] - 26000
-    if cfg.get("round_order") == 1 and dims["rounds"] > 1:
+    if cfg.get("round_order") in (1, 2) and dims["rounds"] > 1:
         # rounds by weight: inside a band no piece of a later round is longer than a piece of an earlier round
         wnp, ps = arr["wave_npieces"].numpy(), arr["piece_slot"].numpy().reshape(dims["n_waves"], cfg["row_cap"])
         nb, wpbr = cfg["n_bands"], cfg["waves_per_band_round"]
@@ -446,7 +452,7 @@ def test_sweep_plan_on_random_small_operators():
         cfg = dict(n_bands=draw(st.sampled_from([1, 2, 3, 8])), waves_per_band_round=draw(st.sampled_from([4, 8])),
                    row_cap=draw(st.sampled_from([1, 2, 5, 78])), piece_cap=draw(st.sampled_from([1, 3, 64])),
                    lookahead=draw(st.sampled_from([4, 64])), sequential=draw(st.sampled_from([0, 1])),
-                   groups=draw(st.sampled_from([2, 4])), round_order=draw(st.sampled_from([0, 1])))
+                   groups=draw(st.sampled_from([2, 4])), round_order=draw(st.sampled_from([0, 1, 2])))
         return n_cols, cols, cfg
 
     @settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
@@ -496,7 +502,7 @@ def test_sweep_plan_argument_errors():
     assert create(waves_per_band_round=6)[0] is False and create(row_cap=0)[0] is False and create(row_cap=255)[0] is False
     assert create(n_bands=0)[0] is False and create(lookahead=2)[0] is False and create(piece_cap=0)[0] is False
     assert create(groups=3)[0] is False and create(groups=2)[0] is True
-    assert create(round_order=2)[0] is False and create(round_order=1)[0] is True
+    assert create(round_order=3)[0] is False and create(round_order=1)[0] is True and create(round_order=2)[0] is True
     assert lib.lgc_sweep_ok(64, 1_693_929, 64) == 4 and lib.lgc_sweep_ok(61, 1000, 64) == 4      # entries per step
     assert lib.lgc_sweep_ok(90, 1000, 96) == 2 and lib.lgc_sweep_ok(80, 1000, 80) == 2 and lib.lgc_sweep_ok(96, 10, 96) == 2
     assert lib.lgc_sweep_ok(100, 1000, 100) == 0 and lib.lgc_sweep_ok(66, 1000, 66) == 0
