@@ -15,6 +15,10 @@ ap.add_argument("--sampler", choices=["uniform", "device", "python"], default="u
                 help="uniform: seeded uniform triples (SURVEY 8d); device: TripleSampler (batch_loader contract on "
                      "the GPU); python: the oracle restatement of the reference's batch_loader on the host")
 ap.add_argument("--adam", choices=["default", "fused"], default="default", help="torch.optim.Adam(fused=...)")
+ap.add_argument("--cpu-reference", type=int, default=0, metavar="THREADS",
+                help="also time the same step on the host with THREADS threads through the oracle's restatement of "
+                     "the reference route (comparison only: BASELINE.json configs[4] quotes steps/s against it); "
+                     "one warm-up step, one timed step")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 g = synth.make_bipartite(**synth.CONFIG_COSMETICS, seed=0)
@@ -62,5 +66,27 @@ for _ in range(3): vals = step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(args.steps): vals = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / args.steps
-print(json.dumps({"metric": "training steps/s (fwd+bwd+Adam, B=%d)" % args.batch, "value": 1 / dt, "ms_per_step": dt * 1e3,
-                  "dim": args.dim, "layers": args.layers, "sampler": args.sampler, "adam": args.adam, "loss": vals[2]}))
+line = {"metric": "training steps/s (fwd+bwd+Adam, B=%d)" % args.batch, "value": 1 / dt, "ms_per_step": dt * 1e3,
+        "dim": args.dim, "layers": args.layers, "sampler": args.sampler, "adam": args.adam, "loss": vals[2]}
+if args.cpu_reference > 0:          # the reference route on the host: unsorted COO, per-layer gcn_norm, autograd, dense Adam
+    from oracle import lightgcn_oracle as oracle
+    torch.set_num_threads(args.cpu_reference)
+    ei_c, ew_c = g.coo()
+    w = torch.nn.Parameter(synth.xavier_table(g.num_nodes, args.dim, 0))
+    alpha = oracle.default_alpha(args.layers)
+    copt = torch.optim.Adam([w], 0.005)
+    cgen = torch.Generator().manual_seed(0)
+    def cpu_step():
+        copt.zero_grad()
+        u = torch.randint(0, g.n_users, (args.batch,), generator=cgen)
+        p = torch.randint(0, g.n_items, (args.batch,), generator=cgen) + g.n_users
+        n = torch.randint(0, g.n_items, (args.batch,), generator=cgen) + g.n_users
+        loss = oracle.train_step_loss(w, alpha, ei_c, ew_c, u, p, n, args.layers, 1e-4)[3]
+        loss.backward()
+        copt.step()
+        return loss.item()
+    cpu_step()
+    t0 = time.perf_counter(); cpu_step(); cdt = time.perf_counter() - t0
+    line["cpu_reference"] = {"steps_per_s": 1 / cdt, "s_per_step": cdt, "threads": args.cpu_reference, "kind": "port",
+                             "speedup": cdt / dt}
+print(json.dumps(line))
