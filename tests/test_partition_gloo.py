@@ -60,7 +60,7 @@ def _worker(rank, world, port, layers, dim, alpha_kind, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,layers,dim,alpha_kind", [(2, 3, 64, "uniform"), (3, 2, 90, "ramp"), (2, 1, 16, "ramp")])
+@pytest.mark.parametrize("world,layers,dim,alpha_kind", [(2, 3, 64, "uniform"), (3, 2, 90, "ramp"), (2, 1, 16, "ramp"), (8, 3, 64, "uniform")])
 def test_partitioned_propagate_matches_single_process_oracle(world, layers, dim, alpha_kind):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
