@@ -838,6 +838,7 @@ struct SweepArgs {
     uint32_t x_bytes;
     int32_t dim, row_cap, n_waves, wave_begin;
     unsigned long long *trace;     // diagnostics only (LGCN_SWEEP_TRACE): [n_waves, 16] s_memrealtime stamps per slab
+    int32_t pstride, pcol;         // partial rows are pstride floats, this launch fills columns pcol .. pcol + dim
 };
 
 template <int Q, int HALF>
@@ -917,7 +918,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, DEPTH
         Acc<4> o;
         o.v[0] = a.x; o.v[1] = a.y; o.v[2] = a.z; o.v[3] = a.w;
         const f4 t = {o.v[0], o.v[1], o.v[2], o.v[3]};
-        __builtin_nontemporal_store(t, reinterpret_cast<f4u *>(p.partials + (int64_t)slots[pc] * p.dim + c0));
+        __builtin_nontemporal_store(t, reinterpret_cast<f4u *>(p.partials + (int64_t)slots[pc] * p.pstride + p.pcol + c0));
     }
 }
 
@@ -2108,8 +2109,12 @@ int lgc_sweep_plan_export(const lgc_sweep_plan *plan, uint32_t *slabs, int32_t *
 
 void lgc_sweep_plan_free(lgc_sweep_plan *plan) { delete plan; }
 
+// 61..64 columns: four table rows per gather instruction.  68..96: two (k_sweep_wide, 96-float accumulators, more rounds).
+// 97..128: the four-row plan again, run twice -- columns [0, 64) and [64, dim) -- into one partial table; measured against
+// the wide sweep this loses at 80 / 90 columns (916 vs 905, 970 vs 951 us per hop), wins at 96 (915 vs 937) and gives
+// 128 columns a sweep at all (1130 vs 1326 us per hop with the chunked item step).
 int lgc_sweep_ok(int32_t dim, int64_t table_rows, int64_t x_stride) {
-    const int groups = (dim >= 61 && dim <= 64) ? 4 : (dim >= 68 && dim <= kWideRow) ? 2 : 0;
+    const int groups = (dim >= 61 && dim <= 64) ? 4 : (dim >= 68 && dim <= kWideRow) ? 2 : (dim > kWideRow && dim <= 128) ? 4 : 0;
     if (groups == 0 || table_rows <= 0 || table_rows >= 0xFFFFFF || x_stride < dim) return 0;
     const int64_t bytes = ((table_rows - 1) * x_stride + dim) * 4;
     const uint32_t pad = (uint32_t)(0xFFFFFFull * (uint64_t)(x_stride * 4));
@@ -2135,7 +2140,12 @@ int lgc_spmm_sweep(const uint32_t *slabs, const int32_t *wave_slab_ptr, const in
     if (lds > 160 * 1024) return LGC_E_INVAL;
     if (n_waves > 0) {
         SweepArgs p{reinterpret_cast<const u4 *>(slabs), wave_slab_ptr, wave_npieces, piece_slot, x, partials, x_stride,
-                    (uint32_t)(((table_rows - 1) * x_stride + dim) * 4), dim, row_cap, (int32_t)n_waves, 0, nullptr};
+                    (uint32_t)(((table_rows - 1) * x_stride + dim) * 4), dim, row_cap, (int32_t)n_waves, 0, nullptr, dim, 0};
+        const bool two_pass = groups == 4 && dim > 64;   // columns [0, 64) and [64, dim) as two sweeps of the same plan
+        if (two_pass) {
+            p.dim = 64;
+            p.x_bytes = (uint32_t)(((table_rows - 1) * x_stride + 64) * 4);
+        }
         if (const char *tr = getenv("LGCN_SWEEP_TRACE")) p.trace = reinterpret_cast<unsigned long long *>(strtoull(tr, nullptr, 0));
         static bool attr_set = false;
         if (!attr_set) {   // more than 64 KiB of dynamic LDS needs the opt-in once per process
@@ -2159,6 +2169,14 @@ int lgc_spmm_sweep(const uint32_t *slabs, const int32_t *wave_slab_ptr, const in
             if (groups == 2) hipLaunchKernelGGL(k_sweep_wide<8>, dim3(blocks), dim3(kBlock), lds, stream, p);
             else if (depth == 16) hipLaunchKernelGGL(k_sweep<16>, dim3(blocks), dim3(kBlock), lds, stream, p);
             else hipLaunchKernelGGL(k_sweep<8>, dim3(blocks), dim3(kBlock), lds, stream, p);
+            if (two_pass) {
+                SweepArgs q = p;
+                q.x = x + 64;
+                q.dim = dim - 64;
+                q.x_bytes = (uint32_t)(((table_rows - 1) * x_stride + (dim - 64)) * 4);
+                q.pcol = 64;
+                hipLaunchKernelGGL(k_sweep<8>, dim3(blocks), dim3(kBlock), lds, stream, q);
+            }
         }
     }
     DimCfg cfg;

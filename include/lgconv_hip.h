@@ -180,7 +180,7 @@ int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries,
  *   lgc_sweep_plan_free
  * The caller uploads the arrays and passes device pointers to lgc_spmm_sweep, with a scratch `partials` of
  * n_slots * dim floats.  The rows of `multi` may be split over two lists: `multi` (one lane group per row, for rows
- * with few slots) and `multi_wide` (one wavefront per row, for rows cut into many pieces); every row in exactly one.  lgc_sweep_ok says whether a table qualifies (61..64 columns, < 2^24 - 1 rows, < 4 GiB).
+ * with few slots) and `multi_wide` (one wavefront per row, for rows cut into many pieces); every row in exactly one.  lgc_sweep_ok says whether a table qualifies (< 2^24 - 1 rows, < 4 GiB) and with which plan: 4 (entries per step) for 61..64 columns and for 97..128 columns (the same plan run twice, columns [0, 64) and [64, dim)), 2 for 68..96 columns, 0 = no sweep.
  */
 typedef struct lgc_sweep_cfg {
     int32_t n_bands;               /* 8: one band per XCD (blockIdx % 8)                               */

@@ -505,7 +505,8 @@ def test_sweep_plan_argument_errors():
     assert create(round_order=3)[0] is False and create(round_order=1)[0] is True and create(round_order=2)[0] is True
     assert lib.lgc_sweep_ok(64, 1_693_929, 64) == 4 and lib.lgc_sweep_ok(61, 1000, 64) == 4      # entries per step
     assert lib.lgc_sweep_ok(90, 1000, 96) == 2 and lib.lgc_sweep_ok(80, 1000, 80) == 2 and lib.lgc_sweep_ok(96, 10, 96) == 2
-    assert lib.lgc_sweep_ok(100, 1000, 100) == 0 and lib.lgc_sweep_ok(66, 1000, 66) == 0
+    assert lib.lgc_sweep_ok(100, 1000, 100) == 4 and lib.lgc_sweep_ok(128, 1000, 128) == 4    # the 4-entry plan, two passes
+    assert lib.lgc_sweep_ok(129, 1000, 129) == 0 and lib.lgc_sweep_ok(66, 1000, 66) == 0
     assert lib.lgc_sweep_ok(64, 1 << 24, 64) == 0 and lib.lgc_sweep_ok(64, 1000, 32) == 0
     one = ct.c_void_p(256)
     assert lib.lgc_spmm_sweep(one, one, one, one, 6, 78, 4, one, 4, None, 0, one, 1000, one, 64, ct.c_void_p(512), 64, None, 0,

@@ -621,7 +621,7 @@ def test_tampered_saved_graph_is_refused_at_load(device, tmp_path):
     PropGraph.load(path, device)
 
 
-@pytest.mark.parametrize("dim", [64, 61, 90, 80, 96, 68])
+@pytest.mark.parametrize("dim", [64, 61, 90, 80, 96, 68, 100, 128])
 def test_band_sweep_matches_the_oracle_and_the_chunked_path(device, dim, monkeypatch):
     """lgc_spmm_sweep (LDS accumulators per (row, band), column-sorted sums, fixed-order combine) on the item half of a
     bipartite graph, forced on at a size where 'auto' would not pick it: vs the oracle hop (1e-5, norm-wise) and vs the
@@ -636,8 +636,8 @@ def test_band_sweep_matches_the_oracle_and_the_chunked_path(device, dim, monkeyp
     want = oracle.lgconv(x, ei, ew)
     xd, rd = x.to(device), r.to(device)
     monkeypatch.setattr(G, "USE_SWEEP", "1")
-    groups = 4 if dim <= 64 else 2
-    for cfg in (dict(waves_per_band_round=8, row_cap=20, piece_cap=16), dict(waves_per_band_round=4, row_cap=78 if dim <= 64 else 51)):
+    groups = 4 if (dim <= 64 or dim > 96) else 2          # 97..128 columns: the 4-entry plan in two passes
+    for cfg in (dict(waves_per_band_round=8, row_cap=20, piece_cap=16), dict(waves_per_band_round=4, row_cap=78 if groups == 4 else 51)):
         monkeypatch.setattr(G, "SWEEP_CFG", dict(G.SWEEP_CFG, **cfg))
         monkeypatch.setattr(G, "SWEEP_CFG_WIDE", dict(G.SWEEP_CFG_WIDE, **cfg))
         sw = Operator.build(n, op.rowptr, op.entries, nu, n, 32, 256, sweep_cols=(0, nu))
@@ -667,10 +667,10 @@ def test_band_sweep_matches_the_oracle_and_the_chunked_path(device, dim, monkeyp
     chunked.apply(xd, yc)
     assert rel_fro(y[nu:].cpu(), yc[nu:].cpu()) <= 1e-6
     # a width the sweep does not take falls back to the chunked path of the same operator
-    x100 = synth.xavier_table(n, 100, 5, device)
-    y100 = torch.empty_like(x100)
-    sw.apply(x100, y100)
-    assert rel_fro(y100[nu:].cpu(), oracle.lgconv(x100.cpu(), ei, ew)[nu:]) <= TOL
+    x66 = synth.xavier_table(n, 66, 5, device)
+    y66 = torch.empty_like(x66)
+    sw.apply(x66, y66)
+    assert rel_fro(y66[nu:].cpu(), oracle.lgconv(x66.cpu(), ei, ew)[nu:]) <= TOL
 
 
 @pytest.mark.parametrize("rows,cols,k", [(1, 54571, 20), (7, 1000, 5), (3, 300, 256), (5, 64, 64), (2, 5000, 1),

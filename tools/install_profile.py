@@ -21,6 +21,15 @@ for name, dst in ((f"gpurun_out/bench_{tag}.json", f"profiles/{tag}_bench.json")
 t = json.load(open("profiles/traffic.json"))
 t.update(source=f"profiles/{tag}_pmc_summary.json", kernel_source_sha256=h, cosmetics_d64=d["traffic_json"]["hbm_bytes_per_hop"])
 json.dump(t, open("profiles/traffic.json", "w"), indent=1)
+d90 = f"gpurun_out/prof_{tag}_d90"
+if os.path.isfile(f"{d90}/summary.json"):          # the D=90 / K=5 configuration, collected with HOPS=40
+    e = json.load(open(f"{d90}/summary.json"))
+    assert e["traffic_json"]["kernel_source_sha256"] == h
+    shutil.copy(f"{d90}/summary.json", f"profiles/{tag}_d90_pmc_summary.json")
+    shutil.copy(glob.glob(f"{d90}/trace/*/*kernel_stats.csv")[0], f"profiles/{tag}_d90_kernel_stats.csv")
+    t = json.load(open("profiles/traffic.json"))
+    t["cosmetics_d90"] = e["traffic_json"]["hbm_bytes_per_hop"]
+    json.dump(t, open("profiles/traffic.json", "w"), indent=1)
 if old:
     for f in glob.glob(f"profiles/{old}_*"):
         os.remove(f)
