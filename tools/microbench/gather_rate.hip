@@ -27,7 +27,8 @@ __global__ __launch_bounds__(256) void k_gather(const float *__restrict__ table,
     const int g = lane / lanes_per_row, l = lane % lanes_per_row;
     uint32_t seed = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2654435761u + 12345u + g * 97u;   // same within a lane group
     f4 acc = {0, 0, 0, 0};
-    const bool on = lane < active_lanes;
+    // active_lanes < 0: the first -active_lanes lanes of EVERY lane group are on (rows narrower than their lane group)
+    const bool on = active_lanes >= 0 ? lane < active_lanes : l < -active_lanes;
     auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)table, 0, 0xFFFFFFFFu, 0x00020000);
     for (int it = 0; it < iters; it += 8) {
         f4 v[8];
@@ -96,6 +97,16 @@ int main() {
         {"x2 4 rows x 128 B, 2 MB (L2)", 2, 16384, 32, 16, 64},
         {"x1 1 row x 256 B, 2 MB (L2)", 3, 8192, 64, 64, 64},
         {"x1 64 lanes same 16 rows (4 lanes/row x 4 B)", 3, 8192, 64, 4, 64},
+        // miss regimes: what does a gather instruction cost when its rows are 2 lines, 1 line, half a line?
+        {"x4 4 rows x 256 B, 14 MB table (user step)", 0, 54571, 64, 16, 64},
+        {"x4 4 rows x 128 B of 256-B rows, 14 MB", 0, 54571, 64, 16, -8},
+        {"x4 4 rows x 64 B of 256-B rows, 14 MB", 0, 54571, 64, 16, -4},
+        {"x4 8 rows x 128 B, 14 MB table", 0, 109142, 32, 8, 64},
+        {"x4 4 rows x 128 B of 256-B rows, 400 MB", 0, 1600000, 64, 16, -8},
+        {"x4 4 rows x 64 B of 256-B rows, 400 MB", 0, 1600000, 64, 16, -4},
+        {"x4 8 rows x 128 B, 400 MB table", 0, 3200000, 32, 8, 64},
+        {"x4 2 rows x 512 B, 400 MB table", 0, 800000, 128, 32, 64},
+        {"x4 2 rows x 384 B of 512-B rows, 400 MB", 0, 800000, 128, 32, -24},
     };
     hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
     const double clk = prop.clockRate * 1e3;
@@ -107,7 +118,8 @@ int main() {
         else if (c.mode == 2) t = run<2>(table, c.rows, c.row_floats, c.lpr, c.active, iters, out, blocks);
         else t = run<3>(table, c.rows, c.row_floats, c.lpr, c.active, iters, out, blocks);
         const double per_lane = c.mode <= 1 ? 16 : c.mode == 2 ? 8 : 4;
-        const double useful = instrs * c.active * per_lane;
+        const int n_active = c.active >= 0 ? c.active : (64 / c.lpr) * -c.active;
+        const double useful = instrs * n_active * per_lane;
         printf("%-50s %8.1f us  %6.2f TB/s useful  %5.1f ns/instr/CU = %5.1f clk@2.1GHz  %5.1f B/clk/CU\n", c.name, t * 1e6,
                useful / t / 1e12, t / (instrs / 256) * 1e9, t / (instrs / 256) * 2.1e9, useful / t / 256 / 2.1e9);
     }
