@@ -74,6 +74,18 @@ def main():
         med, mn = timed(lambda: op.apply(x, y))
         print(f"item half  users mod {m:7d} ({m * row_b / 1e6:7.2f} MB): {med:8.1f} us (min {mn:.1f})", flush=True)
         del op
+    # the band sweep itself with its gathers folded: what do its steps (slab, broadcast, LDS read-modify-write, partial
+    # write-out, combine) cost when the gathered rows come from L1 / L2?
+    from gnn_ecommerce_amd import graph as G
+    G.USE_SWEEP = "1"
+    for m in (1024, 16384, 131072):
+        ent = item_op.entries.clone()
+        ent[:, 0] = ent[:, 0] % m
+        op = Operator.build(item_op.n_rows, item_op.rowptr, ent, g.n_users, g.num_nodes, 32, 256, sweep_cols=(0, m))
+        med, mn = timed(lambda: op.apply(x, y))
+        print(f"item half  SWEEP, users mod {m:7d} ({m * row_b / 1e6:7.2f} MB): {med:8.1f} us (min {mn:.1f})  "
+              f"rounds {op.sweep_plan(4).dims['rounds']}", flush=True)
+        del op
 
 
 if __name__ == "__main__":
