@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--dim", type=int, default=DIM)
     ap.add_argument("--config", choices=["cosmetics", "small"], default="cosmetics")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-deep", action="store_true", help="skip the configs[2] (D=90, K=5) measurement that rides "
+                    "along on the default single-GPU run")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = auto)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
                     "to rehearse the N > 1 path with several ranks on ONE GPU)")
@@ -163,24 +165,29 @@ def main():
     graph = synth.make_bipartite(**cfg, seed=SEED)
     t_gen = time.perf_counter() - t0
     n, nnz = graph.num_nodes, graph.nnz
-    alphas = tuple([1.0 / (args.layers + 1)] * (args.layers + 1))
-    x0 = synth.xavier_table(n, args.dim, SEED, dev)
     ei, ew = graph.coo(dev)
 
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if world == 1:
         pg = lg.PropGraph(ei, ew, n)
-        step = lambda: propagate.propagate_sum(x0, pg, alphas)
+        torch.cuda.synchronize()
+        t_build = time.perf_counter() - t0
+        # the work plans are built lazily by the first hop: force them here so that their cost is reported instead of
+        # hiding in the warm-up (tile classes on the device; the item half's band-sweep plan: D2H copy, host planner, upload)
+        t0 = time.perf_counter()
+        pg.prepare(args.dim)
+        t_plan = time.perf_counter() - t0
+        make_step = lambda x0, alphas: (lambda: propagate.propagate_sum(x0, pg, alphas))
         parallelism = "single"
     else:
         from gnn_ecommerce_amd.partition import PartitionedPropagator
         pp = PartitionedPropagator(ei, ew, graph.n_users, graph.n_items, rank, world)
-        step = lambda: pp.propagate_sum(x0, alphas)
+        torch.cuda.synchronize()
+        t_build, t_plan = time.perf_counter() - t0, None
+        make_step = lambda x0, alphas: (lambda: pp.propagate_sum(x0, alphas))
         parallelism = (f"user-range x{world}, items replicated, all-reduce [n_items,D]/hop over {args.backend}"
                        + ("" if args.backend == "nccl" else " (rehearsal, not RCCL)"))
-    torch.cuda.synchronize()
-    t_build = time.perf_counter() - t0
     del ei, ew
 
     def fence():
@@ -188,36 +195,62 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    propagate.HOP_EVENT_LOG = []
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    hop_events, propagate.HOP_EVENT_LOG = propagate.HOP_EVENT_LOG, None
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = tmax.item()
+    def measure(dim, layers, steps, warmup):
+        """W untimed steps, then exactly K timed steps between two fences; per-hop events on the launch stream."""
+        alphas = tuple([1.0 / (layers + 1)] * (layers + 1))
+        x0 = synth.xavier_table(n, dim, SEED, dev)
+        step = make_step(x0, alphas)
+        for _ in range(warmup):
+            step()
+        propagate.HOP_EVENT_LOG = []
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        hop_events, propagate.HOP_EVENT_LOG = propagate.HOP_EVENT_LOG, None
+        if world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = tmax.item()
+        hop_ms = [s.elapsed_time(e) for s, e in hop_events]
+        hop_mean_s = sum(hop_ms) / max(len(hop_ms), 1) * 1e-3
+        bmin = synth.algorithmic_bytes_per_layer(n, nnz, dim)
+        achieved = bmin / hop_mean_s if hop_mean_s > 0 else 0.0
+        return {"elapsed": elapsed, "hop_mean_s": hop_mean_s, "launches": len(hop_ms), "bmin": bmin, "achieved": achieved}
 
-    hop_ms = [s.elapsed_time(e) for s, e in hop_events]
-    hop_mean_s = sum(hop_ms) / max(len(hop_ms), 1) * 1e-3
-    bmin = synth.algorithmic_bytes_per_layer(n, nnz, args.dim)
-    achieved = bmin / hop_mean_s if hop_mean_s > 0 else 0.0
-    if rank == 0:
-        # HBM bytes per hop come from separate rocprofv3 PMC passes (profiles/collect.sh); the figure is only quoted
-        # while the kernel source it was measured on is the one running now, otherwise null
-        traffic, traffic_note = None, "no PMC measurement for this kernel source (run profiles/collect.sh)"
+    def traffic_of(dim):
+        """HBM-side bytes per hop from separate rocprofv3 PMC passes (profiles/collect.sh): quoted only while the kernel
+        source they were measured on is the one running now, otherwise null.  Not measured by THIS process."""
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if world == 1 and os.path.isfile(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
             if tj.get("kernel_source_sha256") == kernel_source_hash():
-                traffic = tj.get(f"{args.config}_d{args.dim}")
-                traffic_note = tj.get("source", "")
+                return tj.get(f"{args.config}_d{dim}"), tj.get("source", ""), tj.get("measured_on", "unrecorded")
+        return None, "no PMC measurement for this kernel source (run profiles/collect.sh)", None
+
+    def roofline_of(m, dim, kernel_note):
+        traffic, note, where = traffic_of(dim)
+        return {"bound": "hbm", "achieved": m["achieved"] / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": m["achieved"] / HBM_PEAK, "traffic": traffic, "traffic_source": note,
+                "traffic_measured_on": where, "kernel": kernel_note,
+                "algorithmic_bytes_per_launch": m["bmin"], "launch_ms": m["hop_mean_s"] * 1e3,
+                "launches_timed": m["launches"]}
+
+    main_m = measure(args.dim, args.layers, args.steps, args.warmup)
+    # configs[2] (same graph, 5 layers, emb_dim 90) rides along on the default single-GPU run: it is the configuration
+    # furthest below its roofline, so the driver's own clock sees it too (VERDICT r2, next #2)
+    deep_m = None
+    if world == 1 and args.config == "cosmetics" and (args.layers, args.dim) == (LAYERS, DIM) and not args.no_deep:
+        t0 = time.perf_counter()
+        pg.prepare(90)
+        deep_plan = time.perf_counter() - t0
+        deep_steps = max(5, args.steps // 2)
+        deep_m = measure(90, 5, deep_steps, args.warmup)
+    if rank == 0:
+        elapsed = main_m["elapsed"]
         line = {
             "metric": "edges propagated/sec per LGConv layer",
             "value": nnz * args.layers * args.steps / elapsed,
@@ -233,14 +266,21 @@ def main():
                                    f"{nnz} directed edges, {args.layers} LGConv layers, emb_dim {args.dim}, "
                                    "get_embedding (K hops + fused layer sum)",
                        "parallelism": parallelism, "seed": SEED,
-                       "graph_build_s": round(t_build, 3), "synth_gen_s": round(t_gen, 1)},
-            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_note,
-                         "kernel": "one hop = one LGConv layer: item step k_sweep + k_sweep_combine, user step "
-                                   "k_apply_fused (one launch: tile classes 8|16|32 through the DPP row kernel + chunked rows > 32 entries)",
-                         "algorithmic_bytes_per_launch": bmin, "launch_ms": hop_mean_s * 1e3,
-                         "launches_timed": len(hop_ms)},
+                       "graph_build_s": round(t_build, 3),
+                       "plan_build_s": None if t_plan is None else round(t_plan, 3),
+                       "synth_gen_s": round(t_gen, 1)},
+            "roofline": roofline_of(main_m, args.dim,
+                                    "one hop = one LGConv layer: item step k_sweep + k_sweep_combine, user step "
+                                    "k_apply_fused (one launch: tile classes 8|16|32 through the DPP row kernel + chunked rows > 32 entries)"),
         }
+        if deep_m is not None:
+            line["other_configs"] = [{
+                "workload": f"configs[2]: same graph, 5 LGConv layers, emb_dim 90, get_embedding",
+                "value": nnz * 5 * deep_steps / deep_m["elapsed"], "unit": "edges/s", "steps": deep_steps,
+                "warmup": args.warmup, "ms_per_step": deep_m["elapsed"] / deep_steps * 1e3, "dtype": "f32",
+                "plan_build_s": round(deep_plan, 3),
+                "roofline": roofline_of(deep_m, 90, "one hop: k_sweep_wide + k_sweep_combine, k_apply_fused<2> (two DPP rows "
+                                                    "per table row, 96-float internal row stride)")}]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(graph, args.layers, args.dim, args.cpu_threads)
         print(json.dumps(line), flush=True)

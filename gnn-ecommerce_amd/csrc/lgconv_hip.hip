@@ -870,8 +870,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, DEPTH
     const int slab_end = p.wave_slab_ptr[w + 1];
     if (slab >= slab_end) return;
     u4 nxt = __builtin_nontemporal_load(p.slabs + (int64_t)slab * kWave + lane);
+#ifdef LGC_SWEEP_TRACE
     int tk = 0;
     if (p.trace && lane == 0) p.trace[(int64_t)w * 16 + tk++] = __builtin_amdgcn_s_memrealtime();
+#endif
     for (; slab < slab_end; ++slab) {
         const u4 cur = nxt;
         if (slab + 1 < slab_end) nxt = __builtin_nontemporal_load(p.slabs + (int64_t)(slab + 1) * kWave + lane);
@@ -908,9 +910,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, DEPTH
 #undef LGC_STEP
 #undef LGC_CONSUME
 #undef LGC_ISSUE
+#ifdef LGC_SWEEP_TRACE
         if (p.trace && lane == 0 && tk < 15) p.trace[(int64_t)w * 16 + tk++] = __builtin_amdgcn_s_memrealtime();
+#endif
     }
+#ifdef LGC_SWEEP_TRACE
     if (p.trace && lane == 0) p.trace[(int64_t)w * 16 + 15] = __builtin_amdgcn_s_memrealtime();   // end of the last slab
+#endif
     // write my pieces to their partial slots: lane group g takes pieces g, g + 4, ...
     const int32_t *slots = p.piece_slot + (int64_t)w * p.row_cap;
     for (int pc = g; pc < npieces; pc += 4) {
@@ -2146,7 +2152,9 @@ int lgc_spmm_sweep(const uint32_t *slabs, const int32_t *wave_slab_ptr, const in
             p.dim = 64;
             p.x_bytes = (uint32_t)(((table_rows - 1) * x_stride + 64) * 4);
         }
+#ifdef LGC_SWEEP_TRACE   /* debug builds only (tools/sweep_trace.py): the variable carries a device address */
         if (const char *tr = getenv("LGCN_SWEEP_TRACE")) p.trace = reinterpret_cast<unsigned long long *>(strtoull(tr, nullptr, 0));
+#endif
         static bool attr_set = false;
         if (!attr_set) {   // more than 64 KiB of dynamic LDS needs the opt-in once per process
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<8>), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -514,6 +514,25 @@ class PropGraph:
             self._halves[transpose] = got
         return got
 
+    def prepare(self, dim: int, table_rows: Optional[int] = None, transpose: bool = False) -> "PropGraph":
+        """Build, now, every work plan a propagation of width ``dim`` will use (they are otherwise built lazily inside
+        the first hop): tile classes of the short rows (device index arithmetic + lgc_build_tiles), and for a
+        user|item graph the band-sweep plan of the item half (device -> host copy of its rows, host planner, upload).
+        A serving worker's ``initialize`` and bench.py's ``plan_build_s`` call this; training pays it twice (A and A^T)."""
+        lib = _native.load()
+        rows = self.num_nodes if table_rows is None else int(table_rows)
+        stride = dim if dim % 32 == 0 else (dim + 31) // 32 * 32            # propagate.scratch_table's row stride
+        ops = self.halves(transpose) if self.split is not None else ((self.transpose_op if transpose else self.forward_op),)
+        for op in ops:
+            if op.tiled and dim >= 4:
+                op.tiles
+            if op.sweep_cols is not None:
+                groups = int(lib.lgc_sweep_ok(dim, rows, stride))
+                if groups in (2, 4) and (groups == 4 or SWEEP_WIDE):
+                    op.sweep_plan(groups)
+        torch.cuda.synchronize(self.device)
+        return self
+
     @property
     def transpose_op(self) -> Operator:
         """A^T with the SAME per-edge values (exact adjoint, no symmetry assumption)."""
@@ -564,8 +583,18 @@ class PropGraph:
         if num_edges:
             col = entries[:, 0]
             checks += [col.min() >= 0, col.max() < num_nodes]
+        if split is not None and num_edges:
+            # a stored split that the entries do not honour would make bipartite_sum return wrong tables silently:
+            # rows < split may only hold columns >= split and the reverse
+            rp_ok = bool(((rp[1:] >= rp[:-1]).all() & (rp[0] == 0) & (rp[-1] == num_edges)).item())
+            if rp_ok:
+                e_split = rp[split]                                            # first entry of row `split`
+                pos = torch.arange(num_edges, device=entries.device)
+                user_side = pos < e_split
+                checks.append(torch.where(user_side, entries[:, 0] >= split, entries[:, 0] < split).all())
         if not bool(torch.stack([c.reshape(()) for c in checks]).all().item()):     # one host sync
-            bad("row pointer is not a non-decreasing 0 .. num_edges sequence, or a column id is outside the graph")
+            bad("row pointer is not a non-decreasing 0 .. num_edges sequence, a column id is outside the graph, or "
+                "the stored bipartite split does not separate the rows' columns")
 
     @classmethod
     def load(cls, path: str, device, short_max: int = SHORT_MAX, chunk_len: int = CHUNK_LEN, with_extra: bool = False):

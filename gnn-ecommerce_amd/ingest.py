@@ -40,7 +40,15 @@ class Interactions:
 
     def seen_csr(self):
         """Purchases (weight == 1.0, src/utils_v2.py:104) as a CSR over users: (ptr int64 [n_users + 1], items int64),
-        items of a user ascending and de-duplicated -- the rows of upstream's sparse ``interactions_t``."""
+        items of a user ascending and DE-DUPLICATED.
+
+        Intended difference from upstream, parity unpinned: ``interact_matrix`` (src/utils_v2.py:100-112) keeps a
+        (user, item) pair bought twice as two entries of the sparse ``interactions_t``; ``to_dense()`` sums them to 2
+        and ``pred * (1 - 2)`` then scores that item ``-pred`` instead of 0 (torchserve/lightgcn_handler.py:88,
+        src/lightgcn.py:175).  A list of seen items has no multiplicity: a purchased item is masked to 0 however often
+        it was bought.  On a frame with one row per (user, item) the two agree; the fixtures captured from the
+        reference have no duplicates (tests/golden/make_golden_serve.py drops them before the capture) and
+        tests/test_ingest_serving.py::test_duplicate_purchases_are_masked_once pins what happens here."""
         buy = self.weight == np.float32(1.0)
         key = np.unique(self.user_idx[buy] * self.n_items + self.item_idx[buy])
         u, i = key // self.n_items, key % self.n_items
@@ -85,6 +93,11 @@ def save_serving_graph(path: str, inter: Interactions, graph=None, device=None) 
     if graph is None:
         graph = build_graph(inter, device)
     ptr, items = inter.seen_csr()
+    for name, ids in (("user", inter.user_ids), ("item", inter.item_ids)):
+        if not np.issubdtype(np.asarray(ids).dtype, np.integer):
+            # LabelEncoder accepts strings; a tensor file does not: keep such maps beside the file
+            raise TypeError(f"{name} ids of dtype {np.asarray(ids).dtype} cannot be stored in the graph file: the id maps "
+                            "are int64 tensors -- relabel string ids to integers first and keep that map outside")
     graph.save(path, extra={"user_ids": torch.from_numpy(np.asarray(inter.user_ids, dtype=np.int64)),
                             "item_ids": torch.from_numpy(np.asarray(inter.item_ids, dtype=np.int64)),
                             "seen_ptr": torch.from_numpy(ptr), "seen_items": torch.from_numpy(items)},

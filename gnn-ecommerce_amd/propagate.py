@@ -402,6 +402,24 @@ class SeenLists:
     def __init__(self, ptr: Tensor, items: Tensor, users: Optional[Tensor] = None):
         self.ptr, self.items, self.users = ptr, items, users
 
+    def validate(self, n_users: int, where: str = "purchase lists") -> "SeenLists":
+        """lgc_mask_topk reads ptr[u], ptr[u + 1] and items[ptr[u] .. ptr[u + 1]) on trust: a truncated or stale list
+        (ptr shorter than n_users + 1, not monotone, pointing past ``items``) must end here in a ValueError, not in an
+        out-of-range read on the device.  One host sync; called once per loaded file, not per request."""
+        def bad(msg):
+            raise ValueError(f"{where}: {msg}")
+        if self.ptr.dtype != torch.int64 or self.ptr.dim() != 1 or self.ptr.numel() != n_users + 1:
+            bad(f"ptr must be int64 [{n_users + 1}], got {self.ptr.dtype} {tuple(self.ptr.shape)}")
+        if self.items.dtype != torch.int64 or self.items.dim() != 1:
+            bad(f"items must be a 1-D int64 tensor, got {self.items.dtype} {tuple(self.items.shape)}")
+        if not self.ptr.is_contiguous() or not self.items.is_contiguous():
+            bad("ptr and items must be contiguous")
+        checks = torch.stack([(self.ptr[0] == 0).reshape(()), (self.ptr[-1] == self.items.numel()).reshape(()),
+                              (self.ptr[1:] >= self.ptr[:-1]).all().reshape(())])
+        if not bool(checks.all().item()):
+            bad("ptr is not a non-decreasing 0 .. len(items) sequence")
+        return self
+
     def for_users(self, users: Tensor) -> "SeenLists":
         return SeenLists(self.ptr, self.items, users)
 

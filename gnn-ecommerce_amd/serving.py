@@ -49,9 +49,18 @@ class RecommendHandler:
         if not os.path.isfile(graph_path):
             raise RuntimeError(f"Missing {GRAPH_FILE} (write it once with gnn_ecommerce_amd.ingest.save_serving_graph)")
         self.graph, extra, meta = PropGraph.load(graph_path, self.device, with_extra=True)
-        self.n_users, self.n_items = int(meta["n_users"]), int(meta["n_items"])
-        self.seen_ptr, self.seen_items = extra["seen_ptr"].to(self.device), extra["seen_items"].to(self.device)
-        self.seen = SeenLists(self.seen_ptr, self.seen_items)
+        try:
+            self.n_users, self.n_items = int(meta["n_users"]), int(meta["n_items"])
+            self.seen_ptr, self.seen_items = extra["seen_ptr"].to(self.device), extra["seen_items"].to(self.device)
+        except (KeyError, ValueError) as exc:
+            raise ValueError(f"{graph_path}: not a serving graph ({exc!r} missing or malformed)") from exc
+        # everything the request path takes on trust is checked here, once: node counts against the graph, the stored
+        # user|item split against n_users, and the purchase lists lgc_mask_topk indexes without bounds
+        if self.n_users < 1 or self.n_items < 1 or self.n_users + self.n_items != self.graph.num_nodes:
+            raise ValueError(f"{graph_path}: n_users {self.n_users} + n_items {self.n_items} != {self.graph.num_nodes} nodes")
+        if self.graph.split is not None and self.graph.split != self.n_users:
+            raise ValueError(f"{graph_path}: bipartite split {self.graph.split} != n_users {self.n_users}")
+        self.seen = SeenLists(self.seen_ptr, self.seen_items).validate(self.n_users, graph_path + ": purchase lists")
         state = load_checkpoint(model_pt_path)
         hp = state["hyperparams"]
         self.model = LightGCN(self.n_users + self.n_items, hp["latent_dim"], hp["n_layers"])
@@ -78,6 +87,9 @@ class RecommendHandler:
         return out
 
     def inference(self, data, *args, **kwargs):
+        users = [int(u) for u in data]
+        if any(u < 0 or u >= self.n_users for u in users):      # upstream's embedding gather raises IndexError as well
+            raise IndexError(f"user index outside [0, {self.n_users})")
         with torch.no_grad():
             # the purchase lists stay a CSR on the device; lgc_mask_topk turns the request's rows into LDS bitmasks
             frame = self.model.recommendK(self.graph, None, self.n_users, self.n_items, self.seen, list(data), self.k)

@@ -349,6 +349,38 @@ def test_saved_graph_validation_rejects_tampered_tensors():
             PropGraph.validate_csr(**{**ok, **change})
 
 
+def test_saved_graph_validation_checks_the_stored_split_against_the_entries():
+    """a stale `split` would make bipartite_sum return wrong tables silently."""
+    from gnn_ecommerce_amd import PropGraph
+    # users 0, 1 | items 2, 3: user rows hold item columns and the reverse
+    rowptr = torch.tensor([0, 2, 3, 5, 6], dtype=torch.int32)
+    entries = torch.tensor([[2, 0], [3, 0], [2, 0], [0, 0], [1, 0], [0, 0]], dtype=torch.int32)
+    deg = dis = torch.ones(4)
+    ok = dict(rowptr=rowptr, entries=entries, deg=deg, dis=dis, num_nodes=4, num_edges=6, split=2, where="t")
+    PropGraph.validate_csr(**ok)
+    PropGraph.validate_csr(**{**ok, "split": None})
+    for split in (1, 3):                                   # the stored split does not separate rows from columns
+        with pytest.raises(ValueError, match="split"):
+            PropGraph.validate_csr(**{**ok, "split": split})
+    user_to_user = entries.clone(); user_to_user[0, 0] = 1
+    with pytest.raises(ValueError, match="split"):
+        PropGraph.validate_csr(**{**ok, "entries": user_to_user})
+
+
+def test_purchase_lists_are_validated_before_the_kernel_indexes_them():
+    """lgc_mask_topk reads list_ptr[u], list_ptr[u + 1], list_items[e] without bounds."""
+    from gnn_ecommerce_amd.propagate import SeenLists
+    ptr, items = torch.tensor([0, 2, 2, 5]), torch.tensor([4, 1, 0, 3, 2])
+    assert SeenLists(ptr, items).validate(3).ptr is ptr
+    for bad_ptr, bad_items in ((ptr[:-1], items),                        # shorter than n_users + 1 (truncated file)
+                               (torch.tensor([0, 3, 2, 5]), items),       # not monotone
+                               (torch.tensor([1, 2, 2, 5]), items),       # does not start at 0
+                               (ptr, items[:4]),                          # points past the item list
+                               (ptr.int(), items), (ptr, items.int()), (ptr, items.view(5, 1))):
+        with pytest.raises(ValueError):
+            SeenLists(bad_ptr, bad_items).validate(3)
+
+
 # ----------------------------------------------------------------------------------------------
 # band-sweep planner (host code of the library: runs without a GPU)
 # ----------------------------------------------------------------------------------------------

@@ -30,6 +30,20 @@ def test_relabel_and_layout_equal_the_references():
     assert np.array_equal(rows, z["seen_indices"][0]) and np.array_equal(items, z["seen_indices"][1])
 
 
+def test_duplicate_purchases_are_masked_once():
+    """the list form of the seen-mask has no multiplicity (documented difference from upstream's
+    interact_matrix, which would score a twice-bought item -pred)."""
+    inter = ingest.relabel([10, 10, 10, 20], [7, 7, 8, 7], [1.0, 1.0, 0.5, 1.0])
+    ptr, items = inter.seen_csr()
+    assert ptr.tolist() == [0, 1, 2] and items.tolist() == [0, 0]      # user 0 bought item 0 twice: listed once
+
+
+def test_string_ids_are_refused_with_a_clear_error(tmp_path):
+    inter = ingest.relabel(["a", "b"], ["x", "y"], [1.0, 1.0])
+    with pytest.raises(TypeError, match="id maps"):
+        ingest.save_serving_graph(str(tmp_path / "g.safetensors"), inter, graph=object())
+
+
 def test_csv_reader_parses_only_the_three_columns(tmp_path):
     import pandas as pd
     z = load_golden("ingest_ref")

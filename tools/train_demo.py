@@ -59,7 +59,7 @@ def main():
 
     model = lg.LightGCN(n_users + n_items, args.dim, args.layers).to(dev)
     opt = torch.optim.Adam(model.parameters(), 0.005)
-    n_batch = max(1, len(train) // (args.batch * 4))
+    n_batch = max(1, len(train) // (args.batch * 40))                   # train_lightgcn.py:92: train_size // (B * 40)
     log = []
     for epoch in range(args.epochs):
         model.train(); t0 = time.perf_counter(); losses = []
