@@ -10,10 +10,10 @@ resolves to it through the shim package of that name at the repository root.
 from . import _native
 from .graph import PropGraph, build_row_plan, clear_cache, get_graph
 from .lgconv import LGConv
-from .lightgcn import BPRLoss, LightGCN
+from .lightgcn import BPRLoss, LightGCN, regularization_loss
 from .propagate import check_index_status, hop, pair_dot, propagate_sum
 from .sampler import TripleSampler
 from . import ingest, serving
 
 __all__ = ["LightGCN", "BPRLoss", "LGConv", "PropGraph", "get_graph", "clear_cache", "build_row_plan",
-           "propagate_sum", "hop", "pair_dot", "check_index_status", "TripleSampler", "_native"]
+           "propagate_sum", "hop", "pair_dot", "check_index_status", "TripleSampler", "regularization_loss", "_native"]

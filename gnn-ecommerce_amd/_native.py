@@ -17,7 +17,7 @@ import torch
 LIB_NAME = "liblgconv_hip.so"
 # LGCN_LIB_PATH selects another build of the SAME library (A/B kernel experiments); never a fallback.
 LIB_PATH = os.environ.get("LGCN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", LIB_NAME)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # status bits (include/lgconv_hip.h)
 ST_INDEX_OOB = 1
@@ -87,8 +87,10 @@ SIGNATURES = {
                           c_int32, c_void_p]),
     "lgc_hop_exchange": (c_int, [POINTER(OperatorC), POINTER(OperatorC), c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
                                  c_int64, c_float, c_float, c_int32, c_int32, c_int32, EXCHANGE_FN, c_void_p, c_void_p]),
-    "lgc_seed_push": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p, c_int64, c_int32,
-                              c_void_p]),
+    "lgc_segment_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_int64, c_int64, c_int32, c_int32,
+                                c_void_p]),
+    "lgc_seed_pull": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p,
+                              c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int32, c_void_p]),
     "lgc_lincomb": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p]),
     "lgc_mask_topk": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
                               c_void_p, c_void_p, c_void_p]),
@@ -96,8 +98,6 @@ SIGNATURES = {
                                    c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lgc_pair_dot": (c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                              c_void_p, c_void_p]),
-    "lgc_pair_dot_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p,
-                                      c_int64, c_void_p, c_void_p, c_void_p]),
 }
 
 

@@ -196,6 +196,9 @@ struct SpmmArgs {
     int32_t dim, lpr;  // lanes per row = ceil(dim / VEC)
     int32_t row_begin, row_end, short_max;
     int32_t wt_store;  // 1: output rows leave with write-through (sc1) stores, see store_out
+    // seeded pull (lgc_seed_pull): only columns with col_flag != 0 are gathered, from row col_slot[col] of x
+    const uint8_t *col_flag;
+    const int32_t *col_slot;
 };
 
 // A lane's slice of a row: VEC consecutive floats starting at column c0.
@@ -227,6 +230,20 @@ __device__ __forceinline__ Acc<VEC> load_row(const float *p) {
         o.v[0] = p[0];
     }
     return o;
+}
+
+// The table row an entry gathers.  FILTER (lgc_seed_pull): x is a compact table of seed rows, an entry counts only if
+// its column carries a flag and then reads the compact row col_slot[col]; everything else contributes nothing.
+template <int VEC, bool FILTER, class P>
+__device__ __forceinline__ Acc<VEC> gather_row(const P &p, const float *xb, int32_t col) {
+    if constexpr (!FILTER) {
+        return load_row<VEC>(xb + (int64_t)col * p.x_stride);
+    } else {
+        Acc<VEC> o;
+        o.zero();
+        if (p.col_flag[col]) o = load_row<VEC>(xb + (int64_t)p.col_slot[col] * p.x_stride);
+        return o;
+    }
 }
 
 template <int VEC>
@@ -282,7 +299,7 @@ __device__ __forceinline__ void finish_row(const P &p, int64_t row, int c0, Acc<
 
 // Short rows: one lane group per row, entries in order, 4 gathers in flight per group; the epilogue
 // row is requested before the gathers and consumed after them.
-template <int VEC>
+template <int VEC, bool FILTER = false>
 __device__ __forceinline__ void rows_body(const SpmmArgs &p, int64_t block) {
     const int lane = threadIdx.x & (kWave - 1);
     const int rows_per_wave = kWave / p.lpr;
@@ -305,10 +322,10 @@ __device__ __forceinline__ void rows_body(const SpmmArgs &p, int64_t block) {
     int32_t k = s;
     for (; k + 4 <= e; k += 4) {
         lgc_entry e0 = ent[k], e1 = ent[k + 1], e2 = ent[k + 2], e3 = ent[k + 3];
-        Acc<VEC> x0 = load_row<VEC>(xb + (int64_t)e0.col * p.x_stride);
-        Acc<VEC> x1 = load_row<VEC>(xb + (int64_t)e1.col * p.x_stride);
-        Acc<VEC> x2 = load_row<VEC>(xb + (int64_t)e2.col * p.x_stride);
-        Acc<VEC> x3 = load_row<VEC>(xb + (int64_t)e3.col * p.x_stride);
+        Acc<VEC> x0 = gather_row<VEC, FILTER>(p, xb, e0.col);
+        Acc<VEC> x1 = gather_row<VEC, FILTER>(p, xb, e1.col);
+        Acc<VEC> x2 = gather_row<VEC, FILTER>(p, xb, e2.col);
+        Acc<VEC> x3 = gather_row<VEC, FILTER>(p, xb, e3.col);
         mul_add<VEC>(acc, e0.val, x0);
         mul_add<VEC>(acc, e1.val, x1);
         mul_add<VEC>(acc, e2.val, x2);
@@ -316,7 +333,7 @@ __device__ __forceinline__ void rows_body(const SpmmArgs &p, int64_t block) {
     }
     for (; k < e; ++k) {
         lgc_entry e0 = ent[k];
-        Acc<VEC> x0 = load_row<VEC>(xb + (int64_t)e0.col * p.x_stride);
+        Acc<VEC> x0 = gather_row<VEC, FILTER>(p, xb, e0.col);
         mul_add<VEC>(acc, e0.val, x0);
     }
     finish_row<VEC, SpmmArgs>(p, row, c0, acc, rv);
@@ -324,7 +341,7 @@ __device__ __forceinline__ void rows_body(const SpmmArgs &p, int64_t block) {
 
 // Long rows: one wavefront per chunk.  Lane group g takes entries begin+g, begin+g+G, ...;
 // the G group sums are then added in group order by lane group 0.
-template <int VEC>
+template <int VEC, bool FILTER = false>
 __device__ __forceinline__ void chunks_body(const SpmmArgs &p, const lgc_chunk *__restrict__ chunks, int32_t n_chunks,
                                             float *__restrict__ partials, int64_t block) {
     const int lane = threadIdx.x & (kWave - 1);
@@ -351,10 +368,10 @@ __device__ __forceinline__ void chunks_body(const SpmmArgs &p, const lgc_chunk *
         if (more) { n0 = ent[k]; n1 = ent[k + groups]; n2 = ent[k + 2 * groups]; n3 = ent[k + 3 * groups]; }
         while (more) {
             const lgc_entry e0 = n0, e1 = n1, e2 = n2, e3 = n3;
-            Acc<VEC> x0 = load_row<VEC>(xb + (int64_t)e0.col * p.x_stride);
-            Acc<VEC> x1 = load_row<VEC>(xb + (int64_t)e1.col * p.x_stride);
-            Acc<VEC> x2 = load_row<VEC>(xb + (int64_t)e2.col * p.x_stride);
-            Acc<VEC> x3 = load_row<VEC>(xb + (int64_t)e3.col * p.x_stride);
+            Acc<VEC> x0 = gather_row<VEC, FILTER>(p, xb, e0.col);
+            Acc<VEC> x1 = gather_row<VEC, FILTER>(p, xb, e1.col);
+            Acc<VEC> x2 = gather_row<VEC, FILTER>(p, xb, e2.col);
+            Acc<VEC> x3 = gather_row<VEC, FILTER>(p, xb, e3.col);
             k += step;
             more = k + 3 * groups < ch.end;
             if (more) { n0 = ent[k]; n1 = ent[k + groups]; n2 = ent[k + 2 * groups]; n3 = ent[k + 3 * groups]; }
@@ -365,7 +382,7 @@ __device__ __forceinline__ void chunks_body(const SpmmArgs &p, const lgc_chunk *
         }
         for (; k < ch.end; k += groups) {
             lgc_entry e0 = ent[k];
-            Acc<VEC> x0 = load_row<VEC>(xb + (int64_t)e0.col * p.x_stride);
+            Acc<VEC> x0 = gather_row<VEC, FILTER>(p, xb, e0.col);
             mul_add<VEC>(acc, e0.val, x0);
         }
     }
@@ -393,15 +410,15 @@ __device__ __forceinline__ void chunks_body(const SpmmArgs &p, const lgc_chunk *
 // left each one's ramp-up and tail exposed -- 7 back-to-back launches per hop of 4-45 us each on a rank of
 // an 8-way partition.  The row part here reads its entries through the row pointer; it serves widths below 4 and
 // callers that ask for it -- rows of up to 32 entries normally go through the tiled kernels (lgc_spmm_tiles).
-template <int VEC>
+template <int VEC, bool FILTER = false>
 __global__ __launch_bounds__(kBlock) void k_spmm_hop(SpmmArgs p, const lgc_chunk *__restrict__ chunks,
                                                     int32_t n_chunks, float *__restrict__ partials,
                                                     int32_t chunk_blocks) {
     if ((int32_t)blockIdx.x < chunk_blocks) {
-        chunks_body<VEC>(p, chunks, n_chunks, partials, blockIdx.x);
+        chunks_body<VEC, FILTER>(p, chunks, n_chunks, partials, blockIdx.x);
     } else {
         const int64_t block = (int64_t)blockIdx.x - chunk_blocks;
-        rows_body<VEC>(p, block);
+        rows_body<VEC, FILTER>(p, block);
     }
 }
 
@@ -1164,32 +1181,32 @@ __global__ __launch_bounds__(kBlock) void k_sweep_combine(SpmmArgs p, const lgc_
     finish_row<VEC, SpmmArgs>(p, mr.row, c0, acc, rv);
 }
 
-// Seeded transpose step: y[col] += val * g[s] for every entry (col, val) of row seed_rows[s] -- the first backward hop
-// of a training step, whose incoming gradient has at most 2B non-zero user rows (src/lightgcn.py:123-125 scores 2B
-// pairs): the dense item step would gather 10 M rows of zeros.  One wavefront per seed row, lane groups stride its
-// entries, fp32 atomics into the (pre-zeroed) output rows: a few thousand edges in all.
-__global__ __launch_bounds__(kBlock) void k_seed_push(const int32_t *__restrict__ rowptr, const lgc_entry *__restrict__ entries,
-                                                     const int64_t *__restrict__ seed_rows, const float *__restrict__ seed_vals,
-                                                     int64_t n_seed, int64_t n_rows, float scale, float *__restrict__ y,
-                                                     int64_t y_stride, int32_t dim) {
+// Fixed-order sum of runs: `key` is sorted; position t is a HEAD when key[t] != key[t - 1].  The lane group of a head adds
+// vals[t], vals[t + 1], ... of its run in that order (fp32, sequential) and writes y[dest[t]] = (accumulate ? y[dest[t]]
+// : 0) + scale * sum; positions that are not heads, and heads with dest < 0, write nothing.  Every destination row is
+// owned by one lane group: no atomics, the same bits on every run -- the gradient of a scoring step has a few thousand
+// non-zero rows (src/lightgcn.py:123-125 scores 2B pairs), repeated nodes are summed here instead of by float atomics.
+__global__ __launch_bounds__(kBlock) void k_segment_sum(const int64_t *__restrict__ key, const int64_t *__restrict__ dest,
+                                                       const float *__restrict__ vals, int64_t n, float scale,
+                                                       float *__restrict__ y, int64_t y_stride, int64_t y_rows, int32_t dim,
+                                                       int32_t accumulate) {
     const int lane = threadIdx.x & (kWave - 1);
-    const int64_t s = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x / kWave);
-    if (s >= n_seed) return;
-    const int64_t row = seed_rows[s];
-    if (row < 0 || row >= n_rows) return;
     const int lpr = (dim + 3) / 4, groups = kWave / lpr;
     const int g = lane / lpr, l = lane - g * lpr;
-    if (g >= groups) return;
+    const int64_t t = ((int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x / kWave)) * groups + g;
+    if (g >= groups || t >= n) return;
+    const int64_t k = key[t];
+    if (t > 0 && key[t - 1] == k) return;
+    const int64_t d = dest[t];
+    if (d < 0 || d >= y_rows) return;
     const int c0 = l * 4;
-    float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int i = 0; i < 4; ++i)
-        if (c0 + i < dim) v[i] = __fmul_rn(scale, seed_vals[s * dim + c0 + i]);
-    for (int32_t k = rowptr[row] + g; k < rowptr[row + 1]; k += groups) {
-        const lgc_entry e = entries[k];
-        float *dst = y + (int64_t)e.col * y_stride + c0;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int64_t u = t; u < n && key[u] == k; ++u)
         for (int i = 0; i < 4; ++i)
-            if (c0 + i < dim) atomicAdd(dst + i, __fmul_rn(e.val, v[i]));
-    }
+            if (c0 + i < dim) acc[i] = __fadd_rn(acc[i], vals[u * dim + c0 + i]);
+    float *out = y + d * y_stride + c0;
+    for (int i = 0; i < 4; ++i)
+        if (c0 + i < dim) out[i] = __fadd_rn(accumulate ? out[i] : 0.0f, __fmul_rn(scale, acc[i]));
 }
 
 struct LincombArgs {
@@ -1236,29 +1253,6 @@ __global__ __launch_bounds__(kBlock) void k_pair_dot(const float *__restrict__ e
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if (lane == 0) scores[m] = s;
-}
-
-__global__ __launch_bounds__(kBlock) void k_pair_dot_bwd(const float *__restrict__ gs, const float *__restrict__ emb,
-                                                        int64_t stride, int32_t dim, int64_t n_nodes,
-                                                        const int64_t *__restrict__ idx0,
-                                                        const int64_t *__restrict__ idx1, int64_t n_pairs,
-                                                        float *__restrict__ grad, int32_t *__restrict__ status) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int64_t m = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x / kWave);
-    if (m >= n_pairs) return;
-    const int64_t a = idx0[m], b = idx1[m];
-    if (a < 0 || a >= n_nodes || b < 0 || b >= n_nodes) {
-        if (lane == 0) atomicOr(status, LGC_ST_INDEX_OOB);
-        return;
-    }
-    const float g = gs[m];
-    const float *pa = emb + a * stride, *pb = emb + b * stride;
-    float *ga = grad + a * stride, *gb = grad + b * stride;
-    for (int c = lane; c < dim; c += kWave) {
-        float va = pa[c], vb = pb[c];
-        atomicAdd(ga + c, g * vb);  // global_atomic_add_f32, 256 contiguous bytes per wave-instruction
-        atomicAdd(gb + c, g * va);
-    }
 }
 
 // ----------------------------------------------------------------------------------------
@@ -2119,12 +2113,17 @@ void lgc_sweep_plan_free(lgc_sweep_plan *plan) { delete plan; }
 // 97..128: the four-row plan again, run twice -- columns [0, 64) and [64, dim) -- into one partial table; measured against
 // the wide sweep this loses at 80 / 90 columns (916 vs 905, 970 vs 951 us per hop), wins at 96 (915 vs 937) and gives
 // 128 columns a sweep at all (1130 vs 1326 us per hop with the chunked item step).
-int lgc_sweep_ok(int32_t dim, int64_t table_rows, int64_t x_stride) {
-    const int groups = (dim >= 61 && dim <= 64) ? 4 : (dim >= 68 && dim <= kWideRow) ? 2 : (dim > kWideRow && dim <= 128) ? 4 : 0;
-    if (groups == 0 || table_rows <= 0 || table_rows >= 0xFFFFFF || x_stride < dim) return 0;
+// A table the sweep kernels can address: 24-bit row ids, 32-bit byte offsets, and the padding id 0xFFFFFF out of range.
+static bool sweep_table_ok(int32_t dim, int64_t table_rows, int64_t x_stride) {
+    if (table_rows <= 0 || table_rows >= 0xFFFFFF || x_stride < dim) return false;
     const int64_t bytes = ((table_rows - 1) * x_stride + dim) * 4;
     const uint32_t pad = (uint32_t)(0xFFFFFFull * (uint64_t)(x_stride * 4));
-    return (x_stride * 4 < (1 << 24) && bytes < (int64_t(1) << 32) && (int64_t)pad >= bytes) ? groups : 0;
+    return x_stride * 4 < (1 << 24) && bytes < (int64_t(1) << 32) && (int64_t)pad >= bytes;
+}
+
+int lgc_sweep_ok(int32_t dim, int64_t table_rows, int64_t x_stride) {
+    const int groups = (dim >= 61 && dim <= 64) ? 4 : (dim >= 68 && dim <= kWideRow) ? 2 : (dim > kWideRow && dim <= 128) ? 4 : 0;
+    return groups != 0 && sweep_table_ok(dim, table_rows, x_stride) ? groups : 0;
 }
 
 int lgc_spmm_sweep(const uint32_t *slabs, const int32_t *wave_slab_ptr, const int32_t *wave_npieces, const int32_t *piece_slot,
@@ -2284,14 +2283,46 @@ int lgc_hop_exchange(const lgc_operator *item_op, const lgc_operator *user_op, i
     return lgc_apply(user_op, table_rows, x, x_stride, y, y_stride, r, r_stride, a, b, dim, stream);
 }
 
-int lgc_seed_push(const int32_t *rowptr, const lgc_entry *entries, const int64_t *seed_rows, const float *seed_vals,
-                  int64_t n_seed, int64_t n_rows, float scale, float *y, int64_t y_stride, int32_t dim, void *stream_) {
-    if (!rowptr || !y || n_seed < 0 || n_rows < 0 || dim < 1 || dim > 256 || y_stride < dim) return LGC_E_INVAL;
-    if (n_seed == 0) return 0;
-    if (!seed_rows || !seed_vals || !entries) return LGC_E_INVAL;
-    hipLaunchKernelGGL(k_seed_push, dim3(ceil_div(n_seed, kBlock / kWave)), dim3(kBlock), 0, as_stream(stream_), rowptr, entries,
-                       seed_rows, seed_vals, n_seed, n_rows, scale, y, y_stride, dim);
+int lgc_segment_sum(const int64_t *key_sorted, const int64_t *dest, const float *vals, int64_t n, float scale, float *y,
+                    int64_t y_stride, int64_t y_rows, int32_t dim, int32_t accumulate, void *stream_) {
+    if (!y || n < 0 || y_rows < 0 || dim < 1 || dim > 256 || y_stride < dim) return LGC_E_INVAL;
+    if (n == 0) return 0;
+    if (!key_sorted || !dest || !vals) return LGC_E_INVAL;
+    const int groups = kWave / ((dim + 3) / 4);
+    hipLaunchKernelGGL(k_segment_sum, dim3(ceil_div(n, (int64_t)(kBlock / kWave) * groups)), dim3(kBlock), 0, as_stream(stream_),
+                       key_sorted, dest, vals, n, scale, y, y_stride, y_rows, dim, accumulate);
     return (int)hipGetLastError();
+}
+
+int lgc_seed_pull(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin, int32_t row_end, int32_t short_max,
+                  const lgc_chunk *chunks, int32_t n_chunks, const lgc_multi_row *multi, int32_t n_multi, float *partials,
+                  const uint8_t *col_flag, const int32_t *col_slot, const float *seed_vals, int64_t seed_stride,
+                  int64_t table_rows, float *y, int64_t y_stride, int32_t dim, void *stream_) {
+    DimCfg cfg;
+    if (!dim_cfg(dim, &cfg)) return LGC_E_DIM;
+    if (!rowptr || !col_flag || !col_slot || !seed_vals || !y || row_begin < 0 || row_end < row_begin || n_chunks < 0 ||
+        n_multi < 0 || short_max < 0 || table_rows < row_end || seed_stride < dim || y_stride < dim)
+        return LGC_E_INVAL;
+    if ((n_chunks > 0 && !chunks) || (n_multi > 0 && (!multi || !partials))) return LGC_E_INVAL;
+    if (!aligned_to(seed_vals, 4) || !aligned_to(y, 4)) return LGC_E_ALIGN;
+    hipStream_t stream = as_stream(stream_);
+    SpmmArgs p{rowptr, entries, seed_vals, y, nullptr, seed_stride, y_stride, 0, 1.0f, 0.0f, dim, cfg.lpr, row_begin, row_end,
+               short_max, 0, col_flag, col_slot};
+    const int waves_per_block = kBlock / kWave;
+    const int rows_per_wave = kWave / cfg.lpr;
+    return dispatch_dim(cfg, [&](auto vec) -> int {
+        constexpr int V = decltype(vec)::value;
+        const int64_t n_rows = (int64_t)row_end - row_begin;
+        const int row_blocks = n_rows > 0 ? ceil_div(ceil_div(n_rows, rows_per_wave), waves_per_block) : 0;
+        const int chunk_blocks = n_chunks > 0 ? ceil_div(n_chunks, waves_per_block) : 0;
+        if (row_blocks + chunk_blocks > 0)
+            hipLaunchKernelGGL((k_spmm_hop<V, true>), dim3(row_blocks + chunk_blocks), dim3(kBlock), 0, stream, p, chunks, n_chunks,
+                               partials, chunk_blocks);
+        if (n_multi > 0)
+            hipLaunchKernelGGL((k_spmm_combine<V>), dim3(ceil_div(n_multi, waves_per_block)), dim3(kBlock), 0, stream, p, multi,
+                               n_multi, partials);
+        return (int)hipGetLastError();
+    });
 }
 
 int lgc_lincomb(float *y, int64_t y_stride, const float *const *src, const int64_t *src_stride, const float *coef,
@@ -2320,17 +2351,6 @@ int lgc_pair_dot(const float *emb, int64_t stride, int32_t dim, int64_t n_nodes,
     if (!idx0 || !idx1 || !scores) return LGC_E_INVAL;
     hipLaunchKernelGGL(k_pair_dot, dim3(ceil_div(n_pairs, kBlock / kWave)), dim3(kBlock), 0, as_stream(stream_), emb,
                        stride, dim, n_nodes, idx0, idx1, n_pairs, scores, status);
-    return (int)hipGetLastError();
-}
-
-int lgc_pair_dot_backward(const float *grad_scores, const float *emb, int64_t stride, int32_t dim, int64_t n_nodes,
-                          const int64_t *idx0, const int64_t *idx1, int64_t n_pairs, float *grad_emb,
-                          int32_t *status, void *stream_) {
-    if (!emb || !grad_emb || !status || dim < 1 || stride < dim || n_nodes < 0 || n_pairs < 0) return LGC_E_INVAL;
-    if (n_pairs == 0) return 0;
-    if (!idx0 || !idx1 || !grad_scores) return LGC_E_INVAL;
-    hipLaunchKernelGGL(k_pair_dot_bwd, dim3(ceil_div(n_pairs, kBlock / kWave)), dim3(kBlock), 0, as_stream(stream_),
-                       grad_scores, emb, stride, dim, n_nodes, idx0, idx1, n_pairs, grad_emb, status);
     return (int)hipGetLastError();
 }
 

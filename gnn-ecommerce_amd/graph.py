@@ -409,9 +409,7 @@ class Operator:
         if not lib.lgc_dim_ok(dim):
             raise _native.NativeLibraryError(f"embedding width {dim} is not supported by the HIP kernels")
         table_rows = min(x.size(0), out.size(0))
-        sweep = int(lib.lgc_sweep_ok(dim, table_rows, x.stride(0))) if self.sweep_cols is not None else 0
-        if sweep == 2 and not SWEEP_WIDE:
-            sweep = 0
+        sweep = sweep_choice(lib, dim, table_rows, x.stride(0)) if self.sweep_cols is not None else 0
         c = self.c_struct(dim, sweep)
         with torch.cuda.device(x.device):
             code = lib.lgc_apply(ctypes.byref(c), table_rows, _native.ptr(x), x.stride(0), _native.ptr(out), out.stride(0),
@@ -419,6 +417,12 @@ class Operator:
                                  _native.stream_of(x.device))
         _native.check(code, "lgc_apply")
         return out
+
+
+def sweep_choice(lib, dim: int, table_rows: int, stride: int) -> int:
+    """Which band-sweep plan a gathered table of this width gets: 4 / 2 (entries per step), 0 = chunk path."""
+    sweep = int(lib.lgc_sweep_ok(dim, table_rows, stride))
+    return 0 if (sweep == 2 and not SWEEP_WIDE) else sweep
 
 
 def _check_table(t: Tensor, name: str) -> None:
@@ -527,8 +531,8 @@ class PropGraph:
             if op.tiled and dim >= 4:
                 op.tiles
             if op.sweep_cols is not None:
-                groups = int(lib.lgc_sweep_ok(dim, rows, stride))
-                if groups in (2, 4) and (groups == 4 or SWEEP_WIDE):
+                groups = sweep_choice(lib, dim, rows, stride)
+                if groups:
                     op.sweep_plan(groups)
         torch.cuda.synchronize(self.device)
         return self

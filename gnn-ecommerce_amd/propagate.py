@@ -245,17 +245,28 @@ class _PairDot(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_scores: Tensor):
-        lib = _native.load()
         emb, idx0, idx1 = ctx.saved_tensors
+        n = emb.size(0)
+        ok = (idx0 >= 0) & (idx0 < n) & (idx1 >= 0) & (idx1 < n)       # invalid pairs scored NaN and carry no gradient
+        i0, i1 = idx0.clamp(0, n - 1), idx1.clamp(0, n - 1)
+        gs = torch.where(ok, grad_scores, torch.zeros_like(grad_scores)).unsqueeze(1)
+        rows = torch.cat([i0, i1])
+        vals = torch.cat([gs * emb[i1], gs * emb[i0]])                   # d score / d emb[i0] = emb[i1] and the reverse
         grad = torch.zeros_like(emb)
-        gs = grad_scores.contiguous()
-        with torch.cuda.device(emb.device):
-            code = lib.lgc_pair_dot_backward(_native.ptr(gs), _native.ptr(emb), emb.stride(0), emb.size(1),
-                                             emb.size(0), _native.ptr(idx0), _native.ptr(idx1), idx0.numel(),
-                                             _native.ptr(grad), _native.ptr(_status(emb.device)),
-                                             _native.stream_of(emb.device))
-        _native.check(code, "lgc_pair_dot_backward")
+        rows_s, perm = torch.sort(rows, stable=True)                     # repeated nodes add up in position order
+        segment_sum(rows_s, rows_s, vals[perm].contiguous(), grad)
         return grad, None, None
+
+
+def segment_sum(key_sorted: Tensor, dest: Tensor, vals: Tensor, out: Tensor, scale: float = 1.0, accumulate: bool = False) -> None:
+    """out[dest[t]] (+)= scale * (sum of vals over the run of equal keys that starts at t), for every run head t with
+    dest[t] >= 0: lgc_segment_sum -- one lane group per destination row, fixed order, no atomics."""
+    lib = _native.load()
+    with torch.cuda.device(out.device):
+        code = lib.lgc_segment_sum(_native.ptr(key_sorted), _native.ptr(dest), _native.ptr(vals), key_sorted.numel(), float(scale),
+                                   _native.ptr(out), out.stride(0), out.size(0), out.size(1), int(accumulate),
+                                   _native.stream_of(out.device))
+    _native.check(code, "lgc_segment_sum")
 
 
 # ----------------------------------------------------------------------------------------
@@ -266,52 +277,91 @@ SPARSE_BACKWARD = os.environ.get("LGCN_SPARSE_BACKWARD", "1") == "1"
 SEED_ROWS_FACTOR = int(os.environ.get("LGCN_SEED_ROWS_FACTOR", "32"))
 
 
-def _seed_push(op: Operator, rows: Tensor, vals: Tensor, scale: float, out: Tensor) -> None:
+def _seed_pull(op: Operator, flag: Tensor, slot: Tensor, seed_vals: Tensor, out: Tensor) -> None:
+    """out[rows of op] = sum over the entries whose column carries a flag of val * seed_vals[slot[col]] (lgc_seed_pull):
+    the rows of ``op`` through its row / chunk plan in lgc_spmm's fixed order."""
     lib = _native.load()
+    p = op.plan
     with torch.cuda.device(out.device):
-        code = lib.lgc_seed_push(_native.ptr(op.rowptr), _native.ptr(op.entries), _native.ptr(rows), _native.ptr(vals),
-                                 rows.numel(), op.n_rows, float(scale), _native.ptr(out), out.stride(0), out.size(1),
-                                 _native.stream_of(out.device))
-    _native.check(code, "lgc_seed_push")
+        code = lib.lgc_seed_pull(_native.ptr(op.rowptr), _native.ptr(op.entries), p.row_begin, p.row_end, p.short_max,
+                                 _native.ptr(p.chunks) if p.n_chunks else None, p.n_chunks,
+                                 _native.ptr(p.multi) if p.n_multi else None, p.n_multi, _native.ptr(op.partials(out.size(1))),
+                                 _native.ptr(flag), _native.ptr(slot), _native.ptr(seed_vals), seed_vals.stride(0),
+                                 out.size(0), _native.ptr(out), out.stride(0), out.size(1), _native.stream_of(out.device))
+    _native.check(code, "lgc_seed_pull")
 
 
-def seeded_transpose_sum(graph: PropGraph, rows: Tensor, vals: Tensor, alphas: Sequence[float], n: int) -> Tensor:
+_seed_maps = {}
+
+
+def _seed_map_buffers(device: torch.device, n_cols: int):
+    """Per device: a byte flag and an int32 slot per column, flags all zero between uses (the pull reads a slot only
+    where the flag is set; the flags of a step's seeds are cleared again right after the pull)."""
+    got = _seed_maps.get(device)
+    if got is None or got[0].numel() < n_cols + 1:
+        got = (torch.zeros(n_cols + 1, dtype=torch.uint8, device=device), torch.empty(n_cols + 1, dtype=torch.int32, device=device))
+        _seed_maps[device] = got
+    return got
+
+
+def seeded_transpose_sum(graph: PropGraph, rows: Tensor, vals: Tensor, alphas: Sequence[float], n: int,
+                         extra: Optional[Sequence] = None) -> Tensor:
     """sum_l alpha_l (A^T)^l g for a gradient g given by its non-zero rows (``rows`` int64, repeats add up; ``vals`` [len, D])
     on a user|item graph -- what ``_PropagateSum.backward`` computes from a dense g, without ever forming it:
-      * hop 1, item side: only edges that leave a seed USER matter -> lgc_seed_push over those users' rows of A
-        (A^T[i, u] = A[u, i]) instead of a dense item step gathering 10 M rows of zeros;
+      * the seed is sorted once; repeated rows are summed in position order by lgc_segment_sum (no float atomics anywhere:
+        the gradient has the same bits on every run, like the reference's CPU path);
+      * hop 1, item side: only edges between an item and a seed USER matter -> lgc_seed_pull over the item rows of A^T
+        (an entry counts if its user carries a flag; it then reads that user's row of the compact seed table) instead of
+        a dense item step gathering 10 M rows of zeros;
       * hop 1, user side: the dense user step, reading only the 14 MB item block of g (the rest of that table is never
         initialised, let alone zero-filled);
-      * the alpha_0 g term of the user rows is added to the <= 2B seed rows afterwards instead of being read as a dense
-        epilogue table by the last user step."""
+      * the alpha_0 g term of the user rows is added to the seed rows afterwards instead of being read as a dense
+        epilogue table by the last user step.
+    ``extra``: (rows, vals, scale) triples added to the result's rows the same way -- the regulariser's gradient
+    (LightGCN.regularization_loss), which upstream's autograd materialises as three dense [N, D] tables."""
     k = len(alphas) - 1
     split = graph.split
     dim = vals.size(1)
     dev = vals.device
-    # no compaction (that would be a host sync): a seed of the other side keeps its slot with row -1 / zero values
-    is_user = (rows < split).unsqueeze(1)
-    urows = torch.where(is_user.squeeze(1), rows, torch.full_like(rows, -1))          # lgc_seed_push skips row < 0
-    uvals = torch.where(is_user, vals, torch.zeros_like(vals))
-    irows = torch.where(is_user.squeeze(1), torch.zeros_like(rows), rows - split)
-    ivals = vals - uvals
+    m = rows.numel()
+    rows_s, perm = torch.sort(rows, stable=True)
+    vals_s = vals[perm].contiguous()
+    pos = torch.arange(m, device=dev)
+    head = torch.ones(m, dtype=torch.bool, device=dev)
+    head[1:] = rows_s[1:] != rows_s[:-1]
+    is_user = rows_s < split
+    none = torch.full_like(rows_s, -1)
     g_tab = torch.empty((n, dim), dtype=torch.float32, device=dev)         # only the item block is ever read
-    g_items = g_tab[split:]
-    g_items.zero_()
-    g_items.index_add_(0, irows, ivals)
+    g_tab[split:].zero_()
+    segment_sum(rows_s, torch.where(is_user, none, rows_s), vals_s, g_tab)                  # g[items]
+
+    def add_extra(out: Tensor) -> Tensor:
+        for e_rows, e_vals, e_scale in (extra or ()):
+            e_s, e_perm = torch.sort(e_rows, stable=True)
+            segment_sum(e_s, e_s, e_vals[e_perm].contiguous(), out, scale=e_scale, accumulate=True)
+        return out
+
     if k == 0:
         out = torch.zeros((n, dim), dtype=torch.float32, device=dev)
-        out.index_add_(0, rows, vals, alpha=alphas[0])
-        return out
+        segment_sum(rows_s, rows_s, vals_s, out, scale=alphas[0])
+        return add_extra(out)
+    # compact table of the seed users: slot = position of the run's head
+    gu = torch.empty((m, dim), dtype=torch.float32, device=dev)
+    user_head = is_user & head
+    segment_sum(rows_s, torch.where(user_head, pos, none), vals_s, gu)
+    flag, slot = _seed_map_buffers(dev, split)
+    fidx = torch.where(is_user, rows_s, torch.full_like(rows_s, split))    # non-users park on the spare entry `split`
+    flag[fidx] = 1
+    slot[torch.where(user_head, rows_s, torch.full_like(rows_s, split))] = pos.to(torch.int32)
     user_t, item_t = graph.halves(True)
-    user_fwd, _ = graph.halves(False)
     tables = [g_tab]
     out = None
     for layer in range(1, k + 1):
         with _HopSpan():
             nxt = scratch_table(g_tab)
             if layer == 1:
-                nxt[split:].zero_()
-                _seed_push(user_fwd, urows, uvals, 1.0, nxt)                    # x_1[items] from the seed users
+                _seed_pull(item_t, flag, slot, gu, nxt)                         # x_1[items] from the seed users
+                flag[fidx] = 0
             else:
                 item_t.apply(tables[-1], nxt)
             if layer < k:
@@ -324,16 +374,28 @@ def seeded_transpose_sum(graph: PropGraph, rows: Tensor, vals: Tensor, alphas: S
                 _native.lincomb(mix[split:], [(alphas[l], tables[l - 1][split:]) for l in range(1, k + 1)])
                 _native.lincomb(out[split:], [(alphas[l], tables[l][split:]) for l in range(0, k + 1)])
                 user_t.apply(mix, out, a=1.0)
-                out.index_add_(0, urows.clamp(min=0), uvals, alpha=alphas[0])   # + alpha_0 g on the seed users
-    return out
+                # + alpha_0 g on the seed users (each such row is owned by one lane group: read, add, write)
+                segment_sum(rows_s, torch.where(is_user, rows_s, none), vals_s, out, scale=alphas[0], accumulate=True)
+    return add_extra(out)
+
+
+class RegHook:
+    """Where a regulariser on the layer-0 rows of the SAME weight table hands its gradient to the scoring node of one
+    forward (``LightGCN.regularization_loss``): ``terms`` collects (rows, scale) pairs; the scoring node's backward adds
+    ``grad_of_the_hook * scale * w[rows]`` to the <= 3B rows of the dense gradient it already writes."""
+
+    def __init__(self, weight: Tensor):
+        self.weight, self.token, self.terms, self.spent = weight, None, [], False
 
 
 class _ScoresFromTable(torch.autograd.Function):
     """scores[m] = <out[i0_m], out[i1_m]> with out = sum_l alpha_l A^l w (src/lightgcn.py:121-125) as ONE autograd node:
-    keeps the 2M gathered rows instead of the [N, D] table, and runs the backward pass from the sparse seed."""
+    keeps the 2M gathered rows instead of the [N, D] table, and runs the backward pass from the sparse seed.  Its second
+    output is a zero-valued scalar ``token``: a loss term that depends on ``w`` only through a few of its rows can route
+    its gradient through it (RegHook) instead of through a dense [N, D] tensor of its own."""
 
     @staticmethod
-    def forward(ctx, w: Tensor, graph: PropGraph, alphas: tuple, idx0: Tensor, idx1: Tensor) -> Tensor:
+    def forward(ctx, w: Tensor, graph: PropGraph, alphas: tuple, idx0: Tensor, idx1: Tensor, hook: Optional[RegHook]):
         lib = _native.load()
         emb = _layer_sum(graph, w.detach(), alphas, transpose=False)
         idx0, idx1 = idx0.contiguous(), idx1.contiguous()
@@ -348,22 +410,59 @@ class _ScoresFromTable(torch.autograd.Function):
         ok = (idx0 >= 0) & (idx0 < n) & (idx1 >= 0) & (idx1 < n)       # invalid pairs score NaN and carry no gradient
         i0, i1 = idx0.clamp(0, n - 1), idx1.clamp(0, n - 1)
         ctx.save_for_backward(emb[i0], emb[i1], i0, i1, ok)
-        ctx.graph, ctx.alphas, ctx.n = graph, alphas, n
-        return scores
+        ctx.graph, ctx.alphas, ctx.n, ctx.hook, ctx.width = graph, alphas, n, hook, emb.size(1)
+        ctx.set_materialize_grads(False)                                # an unused output arrives as None, not as zeros
+        return scores, torch.zeros((), dtype=torch.float32, device=emb.device)
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, grad_scores: Tensor):
+    def backward(ctx, grad_scores: Tensor, grad_token: Optional[Tensor]):
         e0, e1, i0, i1, ok = ctx.saved_tensors
+        hook = ctx.hook
+        extra = []
+        if hook is not None:
+            hook.spent = True                                           # later regularisers take the plain torch path
+            if grad_token is not None:
+                w = hook.weight.detach()
+                extra = [(r, w[r] * grad_token, scale) for r, scale in hook.terms]
+        if grad_scores is None:                                          # only the regulariser was differentiated
+            out = torch.zeros((ctx.n, ctx.width), dtype=torch.float32, device=e0.device)
+            for r, v, scale in extra:
+                r_s, perm = torch.sort(r, stable=True)
+                segment_sum(r_s, r_s, v[perm].contiguous(), out, scale=scale, accumulate=True)
+            return out, None, None, None, None, None
         gs = torch.where(ok, grad_scores, torch.zeros_like(grad_scores)).unsqueeze(1)
         rows = torch.cat([i0, i1])                                       # pairs that share a node simply add up
         vals = torch.cat([gs * e1, gs * e0])                             # d score / d out[i0] = e1, d / d out[i1] = e0
-        return seeded_transpose_sum(ctx.graph, rows, vals, ctx.alphas, ctx.n), None, None, None, None
+        return seeded_transpose_sum(ctx.graph, rows, vals, ctx.alphas, ctx.n, extra), None, None, None, None, None
 
 
-def scores_from_table(w: Tensor, graph: PropGraph, alphas: Sequence[float], edge_label_index: Tensor) -> Tensor:
+class _RegThroughHook(torch.autograd.Function):
+    """value = decay/2 * (|w[u]|^2 + |w[p]|^2 + |w[n]|^2) / size (src/utils_v2.py:193-211), differentiable through the
+    scoring node's token: d value / d w[r] = decay / size * w[r] per occurrence of r, added by that node's backward."""
+
+    @staticmethod
+    def forward(ctx, token: Tensor, value: Tensor) -> Tensor:
+        return value + token
+
+    @staticmethod
+    def backward(ctx, grad: Tensor):
+        return grad, None
+
+
+def regularization_through(hook: RegHook, size: int, users: Tensor, pos: Tensor, neg: Tensor, decay: float) -> Tensor:
+    """The regulariser of src/utils_v2.py:193-211 on ``hook.weight``, its gradient routed into the scoring node."""
+    w = hook.weight.detach()
+    value = (1 / 2) * (w[users].norm().pow(2) + w[pos].norm().pow(2) + w[neg].norm().pow(2)) / size * decay
+    hook.terms.append((torch.cat([users.reshape(-1), pos.reshape(-1), neg.reshape(-1)]), float(decay) / float(size)))
+    return _RegThroughHook.apply(hook.token, value)
+
+
+def scores_from_table(w: Tensor, graph: PropGraph, alphas: Sequence[float], edge_label_index: Tensor,
+                      hook: Optional[RegHook] = None) -> Tensor:
     """``pair_dot(propagate_sum(w, graph, alphas), edge_label_index)``; with gradients on, a user|item graph and few
-    label pairs it runs as one node whose backward pass starts from the sparse seed."""
+    label pairs it runs as one node whose backward pass starts from the sparse seed.  ``hook``: filled
+    in (``hook.token``) when that node is used, so that a regulariser can hand it its gradient."""
     _native.require_device(w, "embedding table")
     _native.require_device(edge_label_index, "edge_label_index")
     if edge_label_index.dtype != torch.int64 or edge_label_index.dim() != 2 or edge_label_index.size(0) != 2:
@@ -375,7 +474,10 @@ def scores_from_table(w: Tensor, graph: PropGraph, alphas: Sequence[float], edge
                  and 2 * edge_label_index.size(1) * SEED_ROWS_FACTOR <= w.size(0))   # a seed far smaller than the table
     if not sparse_ok:
         return pair_dot(propagate_sum(w, graph, alphas), edge_label_index)
-    return _ScoresFromTable.apply(w, graph, alphas, edge_label_index[0], edge_label_index[1])
+    scores, token = _ScoresFromTable.apply(w, graph, alphas, edge_label_index[0], edge_label_index[1], hook)
+    if hook is not None:
+        hook.token = token
+    return scores
 
 
 def pair_dot(emb: Tensor, edge_label_index: Tensor) -> Tensor:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LGC_ABI_VERSION 8
+#define LGC_ABI_VERSION 9
 
 /* argument errors (negative return values) */
 #define LGC_E_INVAL      (-1)  /* null pointer, negative size, bad flag                    */
@@ -284,14 +284,25 @@ int lgc_hop_exchange(const lgc_operator *item_op, const lgc_operator *user_op, i
                      int32_t dim, int32_t exchange_row_begin, int32_t exchange_rows, lgc_exchange_fn exchange,
                      void *user, void *stream);
 
-/* Seeded transpose step (first hop of the backward pass, loss.backward() at src/train_lightgcn.py:146): the incoming
- * gradient of the scores of src/lightgcn.py:123-125 has non-zero rows only where a label pair points, so
- *   y[col] += entries[k].val * scale * seed_vals[s]   for every entry k of row seed_rows[s]
- * replaces the dense hop over the whole graph for those rows' side.  y must hold zeros (or the sum to add to);
- * fp32 atomics: the order of the few thousand adds is not fixed.  seed_rows int64 [n_seed] (rows outside
- * [0, n_rows) are skipped), seed_vals fp32 [n_seed, dim] dense. */
-int lgc_seed_push(const int32_t *rowptr, const lgc_entry *entries, const int64_t *seed_rows, const float *seed_vals,
-                  int64_t n_seed, int64_t n_rows, float scale, float *y, int64_t y_stride, int32_t dim, void *stream);
+/* Fixed-order sum of runs -- how the sparse gradient of a scoring step (src/lightgcn.py:123-125 scores 2B pairs; what
+ * autograd's index_select backward does with float atomics at src/train_lightgcn.py:146) is accumulated deterministically:
+ * `key_sorted` int64 [n] is sorted; position t is a head when key[t] != key[t - 1]; for every head with 0 <= dest[t] < y_rows
+ *   y[dest[t]] = (accumulate ? y[dest[t]] : 0) + scale * (vals[t] + vals[t + 1] + ... over the run, in that order)
+ * vals fp32 [n, dim] dense.  One lane group owns a destination row: no atomics, the same bits on every run. */
+int lgc_segment_sum(const int64_t *key_sorted, const int64_t *dest, const float *vals, int64_t n, float scale, float *y,
+                    int64_t y_stride, int64_t y_rows, int32_t dim, int32_t accumulate, void *stream);
+
+/* Seeded pull (first hop of the backward pass, loss.backward() at src/train_lightgcn.py:146): the incoming gradient has
+ * non-zero rows only at a few thousand seed columns, given as a compact table.  The hop of lgc_spmm over rows
+ * [row_begin, row_end) + chunks, in which an entry counts only if col_flag[col] != 0 and then gathers row col_slot[col] of
+ * `seed_vals` (fp32 [n_seed, seed_stride]):   y[row] = sum_{k : col_flag[col_k]} val_k * seed_vals[col_slot[col_k]].
+ * Same fixed summation order as lgc_spmm (entry order per lane group, chunk slots in order): deterministic, where a push
+ * along the seeds' rows needs float atomics.  col_flag uint8 [table_rows], col_slot int32 [table_rows] (read only where
+ * the flag is set). */
+int lgc_seed_pull(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin, int32_t row_end, int32_t short_max,
+                  const lgc_chunk *chunks, int32_t n_chunks, const lgc_multi_row *multi, int32_t n_multi, float *partials,
+                  const uint8_t *col_flag, const int32_t *col_slot, const float *seed_vals, int64_t seed_stride,
+                  int64_t table_rows, float *y, int64_t y_stride, int32_t dim, void *stream);
 
 /* y[i, :dim] = sum_t coef[t] * src[t][i, :dim]  for i < n_rows, terms added in index order, each product
  * rounded before its add -- the order of the reference's running layer sum `out = out + x * alpha`
@@ -309,14 +320,6 @@ int lgc_lincomb(float *y, int64_t y_stride, const float *const *src, const int64
 int lgc_pair_dot(const float *emb, int64_t stride, int32_t dim, int64_t n_nodes,
                  const int64_t *idx0, const int64_t *idx1, int64_t n_pairs,
                  float *scores, int32_t *status, void *stream);
-
-/* Gradient seed of lgc_pair_dot (what autograd builds at src/train_lightgcn.py:146):
- *   grad_emb[idx0[m]] += g[m] * emb[idx1[m]];  grad_emb[idx1[m]] += g[m] * emb[idx0[m]]
- * grad_emb [n_nodes, stride] must be zero-filled by the caller; accumulation uses fp32 atomics. */
-int lgc_pair_dot_backward(const float *grad_scores, const float *emb, int64_t stride,
-                          int32_t dim, int64_t n_nodes,
-                          const int64_t *idx0, const int64_t *idx1, int64_t n_pairs,
-                          float *grad_emb, int32_t *status, void *stream);
 
 /* Serving tail of LightGCN.recommendK (src/lightgcn.py:175-177; called per request from
  * torchserve/lightgcn_handler.py:91): masked = scores * (1 - seen), then per row the k largest by

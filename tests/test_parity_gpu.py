@@ -133,8 +133,15 @@ def test_plan_shapes_do_not_change_the_result(device, short_max, chunk_len):
     assert rel_fro(y, ref) <= TOL and worst_row_rel(y, ref) <= TOL
 
 
+@pytest.mark.parametrize("seeded", [False, True], ids=["dense_backward", "seeded_backward"])
 @pytest.mark.parametrize("name", golden_names("train_"))
-def test_golden_forward_scores_losses_grad(device, name):
+def test_golden_forward_scores_losses_grad(device, name, seeded, monkeypatch):
+    """Scores, losses and embedding.weight.grad of the reference's step on every train_* fixture, through both backward
+    routes: the dense two-node path these small graphs take by default, and (forced) the seeded one-node path with the
+    regulariser's gradient routed through the scoring node."""
+    from gnn_ecommerce_amd import propagate
+    if seeded:
+        monkeypatch.setattr(propagate, "SEED_ROWS_FACTOR", 0)
     z = load_golden(name)
     ei, ew, w0 = t(z["edge_index"]), t(z["edge_weight"]), t(z["weight0"])
     n, dim = w0.shape
@@ -154,7 +161,10 @@ def test_golden_forward_scores_losses_grad(device, name):
     out = model(ei_d, labels, ew_d)
     size = len(users)
     bpr = model.recommendation_loss(out[:size], out[size:], 0) * size
-    reg = oracle.regularization_loss(model.embedding.weight, size, users, pos, neg, z["decay"].item())
+    # the drop-in's regulariser (gradient routed through the scoring node: no dense [N, D] tensors of its own)
+    reg = lg.regularization_loss(model.embedding.weight, size, users, pos, neg, z["decay"].item())
+    assert ("RegThroughHook" in type(reg.grad_fn).__name__) == seeded
+    assert ("ScoresFromTable" in type(out.grad_fn).__name__) == seeded
     (bpr + reg).backward()
     lg.check_index_status()
     assert rel_fro(out.detach().cpu().view(1, -1), t(z["scores"]).view(1, -1)) <= TOL
@@ -164,10 +174,16 @@ def test_golden_forward_scores_losses_grad(device, name):
     assert rel_fro(grad, t(z["grad"])) <= TOL, rel_fro(grad, t(z["grad"]))     # north_star: 1e-5
 
 
-@pytest.mark.parametrize("name", ["train_s0_d64_k3", "train_s1_d90_k5"])
-def test_golden_adam_steps_and_topk(device, name):
-    """The caller harness of src/train_lightgcn.py:130-147 on top of the HIP model: 3 Adam steps."""
+@pytest.mark.parametrize("name", golden_names("train_"))
+def test_golden_adam_steps_and_topk(device, name, monkeypatch):
+    """The caller harness of src/train_lightgcn.py:130-147 on top of the HIP model: 3 Adam steps and recommendK, on
+    every train_* fixture (3 seeds x D in {64, 80, 90} x K in {3, 5}); odd fixtures use upstream's own caller-side
+    regulariser (plain torch ops), even ones the drop-in's (gradient routed through the scoring node)."""
     z = load_golden(name)
+    own_reg = golden_names("train_").index(name) % 2 == 0
+    if own_reg:                      # these small graphs take the dense backward by default: force the seeded node
+        from gnn_ecommerce_amd import propagate
+        monkeypatch.setattr(propagate, "SEED_ROWS_FACTOR", 0)
     ei, ew, w0 = t(z["edge_index"]).to(device), t(z["edge_weight"]).to(device), t(z["weight0"])
     n, dim = w0.shape
     model = lg.LightGCN(n, dim, len(z["alpha"]) - 1)
@@ -190,8 +206,9 @@ def test_golden_adam_steps_and_topk(device, name):
         opt.zero_grad()
         out = model(ei, labels, ew)
         size = len(users)
+        reg_fn = lg.regularization_loss if own_reg else oracle.regularization_loss
         loss = (model.recommendation_loss(out[:size], out[size:], 0) * size
-                + oracle.regularization_loss(model.embedding.weight, size, users, pos, neg, z["decay"].item()))
+                + reg_fn(model.embedding.weight, size, users, pos, neg, z["decay"].item()))
         loss.backward()
         opt.step()
         if step == 0:
@@ -537,6 +554,45 @@ def test_full_scale_properties(device, cosmetics_graph, dim, layers):
     assert torch.equal(pg.deg.cpu(), deg)
 
 
+def test_full_scale_training_step_against_the_oracle(device, cosmetics_graph):
+    """BASELINE.json configs[4]'s step on one GPU (src/train_lightgcn.py:137-147: B = 1024, D = 64, K = 3 on the
+    20.3 M-edge graph), seeded backward on: scores, bpr, reg and embedding.weight.grad against the oracle's
+    train_step_loss + autograd on the host -- whole tensor, the <= 3B seed rows, 20 hub rows."""
+    g = cosmetics_graph
+    ei, ew = g.coo()
+    n, dim, layers, b, decay = g.num_nodes, 64, 3, 1024, 1e-4
+    gen = torch.Generator().manual_seed(11)
+    users = torch.randint(0, g.n_users, (b,), generator=gen)
+    pos = torch.randint(0, g.n_items, (b,), generator=gen) + g.n_users
+    neg = torch.randint(0, g.n_items, (b,), generator=gen) + g.n_users
+    w0 = synth.xavier_table(n, dim, 0)
+    alpha = oracle.default_alpha(layers)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    wr = w0.clone().requires_grad_(True)
+    ref_scores, ref_bpr, ref_reg, ref_loss = oracle.train_step_loss(wr, alpha, ei, ew, users, pos, neg, layers, decay)
+    ref_loss.backward()
+    model = lg.LightGCN(n, dim, layers)
+    model.load_state_dict({"alpha": alpha, "embedding.weight": w0})
+    model.to(device)
+    ud, pd_, nd = users.to(device), pos.to(device), neg.to(device)
+    labels = oracle.batch_pos_neg_edges(ud, pd_, nd)
+    out = model(ei.to(device), labels, ew.to(device))
+    assert "ScoresFromTable" in type(out.grad_fn).__name__                        # the seeded path
+    bpr = model.recommendation_loss(out[:b], out[b:], 0) * b
+    reg = model.regularization_loss(ud, pd_, nd, decay)
+    (bpr + reg).backward()
+    lg.check_index_status()
+    grad = model.embedding.weight.grad.cpu()
+    assert rel_fro(out.detach().cpu().view(1, -1), ref_scores.detach().view(1, -1)) <= TOL
+    assert abs(bpr.item() - ref_bpr.item()) <= 1e-5 * abs(ref_bpr.item())
+    assert abs(reg.item() - ref_reg.item()) <= 1e-5 * abs(ref_reg.item())
+    seeds = torch.unique(torch.cat([users, pos, neg]))
+    hubs = torch.topk(torch.bincount(ei[1], minlength=n), 20).indices
+    fro, seed_err, hub_err = rel_fro(grad, wr.grad), rel_fro(grad[seeds], wr.grad[seeds]), worst_row_rel(grad[hubs], wr.grad[hubs])
+    print(f"full-size training step: grad fro {fro:.2e}  seed rows {seed_err:.2e}  hub rows {hub_err:.2e}")
+    assert fro <= TOL and seed_err <= TOL and hub_err <= TOL
+
+
 def test_end_to_end_caller_loop_learns(device):
     """The reference's whole caller loop (sampler -> step -> recommendK -> MARK_MAPK, tools/train_demo.py) on
     synthetic latent-factor data: the BPR loss falls and recall@20 on held-out purchases beats chance by far."""
@@ -767,8 +823,9 @@ def test_recommendk_frame_is_upstreams_frame(device):
 @pytest.mark.parametrize("dim,layers", [(64, 3), (90, 5), (16, 1), (64, 0)])
 def test_seeded_backward_equals_the_dense_backward_and_the_oracle(device, dim, layers, monkeypatch):
     """LightGCN.forward as one autograd node whose backward starts from the <= 2M seed rows
-    (lgc_seed_push for the first item step, no dense zero-filled gradient) vs the dense two-node path and the oracle's
-    autograd; duplicated nodes in the label pairs, an out-of-range pair, and the regulariser's dense gradient added."""
+    (lgc_seed_pull for the first item step, lgc_segment_sum for repeated nodes: no dense zero-filled gradient, no float
+    atomics) vs the dense two-node path and the oracle's autograd; duplicated nodes in the label pairs, an out-of-range
+    pair, and the regulariser both as upstream's caller-side expression and routed through the scoring node."""
     from gnn_ecommerce_amd import propagate
     g, ei, ew = small_graph(13, 900, 140, 9000)
     n = g.num_nodes
@@ -789,16 +846,26 @@ def test_seeded_backward_equals_the_dense_backward_and_the_oracle(device, dim, l
         model.load_state_dict({"alpha": alpha, "embedding.weight": w0})
         model.to(device)
         out = model(ei.to(device), labels.to(device), ew.to(device))
-        loss = model.recommendation_loss(out[:b], out[b:], 0) * b \
-            + oracle.regularization_loss(model.embedding.weight, b, users.to(device), pos.to(device), neg.to(device), 1e-4)
+        reg_fn = lg.regularization_loss if own_reg else oracle.regularization_loss
+        reg = reg_fn(model.embedding.weight, b, users.to(device), pos.to(device), neg.to(device), 1e-4)
+        loss = model.recommendation_loss(out[:b], out[b:], 0) * b + reg
         loss.backward()
-        return out.detach().cpu(), model.embedding.weight.grad.cpu(), out.grad_fn
+        return out.detach().cpu(), model.embedding.weight.grad.cpu(), out.grad_fn, reg
 
-    s_out, s_grad, s_fn = run(0)                     # seeded
-    d_out, d_grad, d_fn = run(10 ** 9)               # dense
+    own_reg = False
+    s_out, s_grad, s_fn, s_reg = run(0)              # seeded, upstream's caller-side regulariser
+    d_out, d_grad, d_fn, _ = run(10 ** 9)            # dense
+    own_reg = True
+    h_out, h_grad, _, h_reg = run(0)                 # seeded, the regulariser's gradient handed to the scoring node
+    f_out, f_grad, _, f_reg = run(10 ** 9)           # dense two-node path: the drop-in regulariser falls back to torch ops
     assert "ScoresFromTable" in type(s_fn).__name__ and "ScoresFromTable" not in type(d_fn).__name__
-    assert torch.equal(s_out, d_out)
+    assert "RegThroughHook" in type(h_reg.grad_fn).__name__ and "RegThroughHook" not in type(f_reg.grad_fn).__name__
+    assert torch.equal(s_out, d_out) and torch.equal(h_out, s_out)
+    assert torch.equal(h_reg.detach(), s_reg.detach())
     assert rel_fro(s_grad, d_grad) <= 2e-6 and worst_row_rel(s_grad, d_grad) <= TOL
+    assert rel_fro(h_grad, s_grad) <= 2e-6 and worst_row_rel(h_grad, s_grad) <= TOL and rel_fro(f_grad, d_grad) <= 2e-6
+    # no float atomics on either path: the same bits on every run
+    assert torch.equal(run(0)[1], h_grad) and torch.equal(run(10 ** 9)[1], f_grad)
     wr = w0.clone().requires_grad_(True)
     _, _, _, ref_loss = oracle.train_step_loss(wr, alpha, ei, ew, users, pos, neg, layers, 1e-4)
     ref_loss.backward()

@@ -15,6 +15,9 @@ ap.add_argument("--sampler", choices=["uniform", "device", "python"], default="u
                 help="uniform: seeded uniform triples (SURVEY 8d); device: TripleSampler (batch_loader contract on "
                      "the GPU); python: the oracle restatement of the reference's batch_loader on the host")
 ap.add_argument("--adam", choices=["default", "fused"], default="default", help="torch.optim.Adam(fused=...)")
+ap.add_argument("--reg", choices=["caller", "routed"], default="routed",
+                help="caller: upstream's regularization_loss on plain torch ops (three dense [N, D] gradients); routed: "
+                     "gnn_ecommerce_amd.regularization_loss (same value, gradient added inside the scoring node)")
 ap.add_argument("--cpu-reference", type=int, default=0, metavar="THREADS",
                 help="also time the same step on the host with THREADS threads through the oracle's restatement of "
                      "the reference route (comparison only: BASELINE.json configs[4] quotes steps/s against it); "
@@ -57,7 +60,10 @@ def step():
     size = len(u)
     bpr = model.recommendation_loss(out[:size], out[size:], 0) * size
     w = model.embedding.weight
-    reg = 0.5 * (w[u].norm().pow(2) + w[p].norm().pow(2) + w[n].norm().pow(2)) / size * 1e-4
+    if args.reg == "routed":
+        reg = lg.regularization_loss(w, size, u, p, n, 1e-4)
+    else:
+        reg = 0.5 * (w[u].norm().pow(2) + w[p].norm().pow(2) + w[n].norm().pow(2)) / size * 1e-4
     loss = bpr + reg
     loss.backward()
     opt.step()
@@ -67,7 +73,7 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(args.steps): vals = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / args.steps
 line = {"metric": "training steps/s (fwd+bwd+Adam, B=%d)" % args.batch, "value": 1 / dt, "ms_per_step": dt * 1e3,
-        "dim": args.dim, "layers": args.layers, "sampler": args.sampler, "adam": args.adam, "loss": vals[2]}
+        "dim": args.dim, "layers": args.layers, "sampler": args.sampler, "adam": args.adam, "reg": args.reg, "loss": vals[2]}
 if args.cpu_reference > 0:          # the reference route on the host: unsorted COO, per-layer gcn_norm, autograd, dense Adam
     from oracle import lightgcn_oracle as oracle
     torch.set_num_threads(args.cpu_reference)
