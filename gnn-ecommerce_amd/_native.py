@@ -26,7 +26,7 @@ ST_SAMPLER_EXHAUSTED = 2
 class SweepCfg(Structure):
     """lgc_sweep_cfg"""
     _fields_ = [("n_bands", c_int32), ("waves_per_band_round", c_int32), ("row_cap", c_int32), ("piece_cap", c_int32),
-                ("lookahead", c_int32), ("sequential", c_int32), ("groups", c_int32), ("round_order", c_int32)]
+                ("lookahead", c_int32), ("groups", c_int32), ("round_order", c_int32)]
 
 
 class SweepDims(Structure):
@@ -72,7 +72,7 @@ SIGNATURES = {
                          c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float, c_float,
                          c_int32, c_void_p]),
     "lgc_build_tiles": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
-    "lgc_spmm_tiles": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int64, c_void_p, c_int64,
+    "lgc_spmm_tiles": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int64, c_void_p, c_int64,
                                c_void_p, c_int64, c_void_p, c_int64, c_float, c_float, c_int32, c_void_p]),
     "lgc_sweep_plan_create": (c_void_p, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, POINTER(SweepCfg),
                                          POINTER(c_int)]),
@@ -86,7 +86,7 @@ SIGNATURES = {
     "lgc_apply": (c_int, [POINTER(OperatorC), c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float, c_float,
                           c_int32, c_void_p]),
     "lgc_hop_exchange": (c_int, [POINTER(OperatorC), POINTER(OperatorC), c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
-                                 c_int64, c_float, c_float, c_int32, c_int32, c_int32, EXCHANGE_FN, c_void_p, c_void_p]),
+                                 c_int64, c_float, c_float, c_int32, c_int32, c_int32, c_int32, EXCHANGE_FN, c_void_p, c_void_p]),
     "lgc_segment_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_int64, c_int64, c_int32, c_int32,
                                 c_void_p]),
     "lgc_seed_pull": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p,

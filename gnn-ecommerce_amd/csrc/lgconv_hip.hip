@@ -483,10 +483,6 @@ __global__ __launch_bounds__(kBlock) void k_spmm_combine(SpmmArgs p, const lgc_m
 // the old one-batch-per-wave kernel kept a wave slot busy ~6 us for 1.3 KB of traffic whatever the gathers hit
 // (tools/exp_floor.py).  No row pointer is read: padding entries carry col = -1.
 //
-// parts = 2 (D a multiple of 64): the row is cut into two column halves of whole 128-B lines; workgroups on
-// XCDs 0-3 (blockIdx % 8) compute the first half of every row, XCDs 4-7 the second, so each XCD's L2 only
-// ever sees half of the gathered table's bytes.  Placement is a speed matter only: any mapping of workgroups
-// to XCDs gives the same result.
 struct TileArgs {
     const int32_t *order;   // [n_tiles * R] row ids in processing order, -1 = padding slot
     const int32_t *meta;    // [n_tiles] 4 x 8 bits: longest row of batch 0..3 of the tile (fast path only)
@@ -498,8 +494,7 @@ struct TileArgs {
     int64_t x_stride, y_stride, r_stride;
     float a, b;
     int32_t n_tiles, tiles_per_wave;
-    int32_t parts, lpr;     // lanes per (part of a) row
-    int32_t part_col[2], part_dim[2];
+    int32_t dim, lpr;       // columns, lanes per row
     int32_t wt_store;
 };
 
@@ -509,23 +504,16 @@ __device__ __forceinline__ void tiles_body(const TileArgs &p, const int64_t bloc
     constexpr int Wk = W / L;          // entries of a row in one load
     constexpr int PPR = Wk / 2;        // 16-byte pieces of a row in one load
     const int lane = threadIdx.x & (kWave - 1);
-    int part = 0;
-    int64_t pblock = block;
-    if (p.parts == 2) {
-        const int xcd = (int)(block & 7);
-        part = xcd >> 2;
-        pblock = (block >> 3) * 4 + (xcd & 3);
-    }
-    const int64_t wave = pblock * (kBlock / kWave) + (threadIdx.x / kWave);
+    const int64_t wave = block * (kBlock / kWave) + (threadIdx.x / kWave);
     int64_t tile = wave * p.tiles_per_wave;
     if (tile >= p.n_tiles) return;  // wave-uniform
     const int64_t tile_end = min(tile + (int64_t)p.tiles_per_wave, (int64_t)p.n_tiles);
-    const int dim = p.part_dim[part];
+    const int dim = p.dim;
     const int G = kWave / p.lpr;       // rows per batch
     const int g = lane / p.lpr;
     const int l = lane - g * p.lpr;
     const bool lane_on = g < G;
-    const int c0 = p.part_col[part] + min(l * 4, dim - 4);
+    const int c0 = min(l * 4, dim - 4);
     const float *xb = p.x + c0;
 
     u4 nxt[L];
@@ -599,6 +587,12 @@ __global__ __launch_bounds__(kBlock) void k_rows_tile(TileArgs p) {
 //     a padding entry / padding row has the 24-bit id 0xFFFFFF, whose offset the host has checked to lie
 //     beyond the table: the hardware returns zeros for the load and drops the store;
 //   * how many entries a batch needs is wave-uniform metadata -> scalar branches.
+// Cache policy of the tiled rows' output stores: nt (2).  Alone, nt stores are the slowest flavour (5.6 TB/s against
+// 8.5-8.7 for plain / sc1, tools/microbench/line_cost.hip), but beside gathers they cost the least: the user step takes
+// 240 us with nt, 245 with sc1 / sc0 sc1, 249 plain (plain also lets the written lines evict gathered rows: 1.14 GB
+// fetched instead of 1.00, profiles/r03a_variants_traffic.txt).
+constexpr int kTileStoreAux = 2;
+
 template <int K>
 __device__ __forceinline__ int bcast16(int v) {
     return __builtin_amdgcn_update_dpp(0, v, 0x150 + K, 0xf, 0xf, true);   // row_newbcast:K (gfx90a+)
@@ -641,7 +635,7 @@ __device__ __forceinline__ void tiles_body_dpp(const TileArgs &p, const int64_t 
     if (tile >= p.n_tiles) return;  // wave-uniform
     const int64_t tile_end = min(tile + (int64_t)p.tiles_per_wave, (int64_t)p.n_tiles);
     const int l = lane & 15;
-    const int c0 = min(l * 4, p.part_dim[0] - 4);
+    const int c0 = min(l * 4, p.dim - 4);
     const auto xsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, p.x_bytes, 0x00020000);
     const auto ysrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.y, 0, p.y_bytes, 0x00020000);
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.r, 0, p.r != nullptr ? p.r_bytes : 0u, 0x00020000);
@@ -715,10 +709,7 @@ __device__ __forceinline__ void tiles_body_dpp(const TileArgs &p, const int64_t 
             }
             const f4 o = {acc.v[0], acc.v[1], acc.v[2], acc.v[3]};
             // sc1 write-through: the output row is not read again in this launch (the host made sure of < 4 GiB)
-#ifndef LGC_STORE_AUX
-#define LGC_STORE_AUX 2     /* nt: output rows are not read again in this launch (sc1 569, plain 574, nt 561 us per hop) */
-#endif
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o), ysrc, __umul24(row24, ys) + xoff, 0, LGC_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o), ysrc, __umul24(row24, ys) + xoff, 0, kTileStoreAux);
         }
     }
 }
@@ -740,7 +731,7 @@ __device__ __forceinline__ void tiles_body_dpp_wide(const TileArgs &p, const int
     if (tile >= p.n_tiles) return;  // wave-uniform
     const int64_t tile_end = min(tile + (int64_t)p.tiles_per_wave, (int64_t)p.n_tiles);
     const int l = lane & 15, pair = lane >> 5, half = (lane >> 4) & 1;
-    const int dim = p.part_dim[0];
+    const int dim = p.dim;
     const int rest = dim - 64;                                   // 4 .. 64 columns in the second DPP row
     const bool lane_on = half == 0 || l * 4 < rest;              // ceil(rest / 4) lanes, the last one overlapping
     const int c0 = half == 0 ? l * 4 : 64 + min(l * 4, rest - 4);
@@ -810,7 +801,7 @@ __device__ __forceinline__ void tiles_body_dpp_wide(const TileArgs &p, const int
                     acc.v[3] = __fadd_rn(acc.v[3], __fmul_rn(p.b, rv.w));
                 }
                 const f4 o = {acc.v[0], acc.v[1], acc.v[2], acc.v[3]};
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o), ysrc, __umul24(row24, ys) + xoff, 0, LGC_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o), ysrc, __umul24(row24, ys) + xoff, 0, kTileStoreAux);
             }
         }
     }
@@ -818,7 +809,7 @@ __device__ __forceinline__ void tiles_body_dpp_wide(const TileArgs &p, const int
 
 template <int W, int L>
 __global__ __launch_bounds__(kBlock) void k_rows_tile_dpp(TileArgs p) {
-    if (p.part_dim[0] > 64) tiles_body_dpp_wide<W, L>(p, blockIdx.x);
+    if (p.dim > 64) tiles_body_dpp_wide<W, L>(p, blockIdx.x);
     else tiles_body_dpp<W, L>(p, blockIdx.x);
 }
 
@@ -841,9 +832,6 @@ __global__ __launch_bounds__(kBlock) void k_rows_tile_dpp(TileArgs p) {
 //     entries (col = 0xFFFFFF, out of range: zeros) update a dummy LDS row;
 //   * at the end a wave writes its pieces to their partial slots (contiguous per output row, band-major) and
 //     k_spmm_combine adds a row's slots in that fixed order: deterministic, no float atomics.
-#ifndef LGC_SWEEP_GATHER_AUX
-#define LGC_SWEEP_GATHER_AUX 0
-#endif
 struct SweepArgs {
     const u4 *slabs;               // [n_slabs * 64]
     const int32_t *wave_slab_ptr;  // [n_waves + 1]
@@ -865,7 +853,7 @@ __device__ __forceinline__ void sweep_fetch(const u4 &cur, int &packed, int &val
 }
 
 template <int DEPTH>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, DEPTH == 16 ? 4 : 8))) void k_sweep(SweepArgs p) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 8))) void k_sweep(SweepArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = threadIdx.x / kWave;
@@ -901,7 +889,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, DEPTH
     {                                                                                                                  \
         sweep_fetch<((S) >> 1), ((S) & 1)>(cur, pk[(S) % DEPTH], vb[(S) % DEPTH]);                                     \
         xv[(S) % DEPTH] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(                                \
-            xsrc, __umul24(pk[(S) % DEPTH] & 0xFFFFFF, xs) + xoff, 0, LGC_SWEEP_GATHER_AUX));                          \
+            xsrc, __umul24(pk[(S) % DEPTH] & 0xFFFFFF, xs) + xoff, 0, 0));                          \
     }
 #define LGC_CONSUME(S)                                                                                                 \
     {                                                                                                                  \
@@ -917,9 +905,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, DEPTH
     LGC_CONSUME(S)                                                                                                     \
     if constexpr ((S) + DEPTH < 32) LGC_ISSUE((S) + DEPTH)
         LGC_ISSUE(0) LGC_ISSUE(1) LGC_ISSUE(2) LGC_ISSUE(3) LGC_ISSUE(4) LGC_ISSUE(5) LGC_ISSUE(6) LGC_ISSUE(7)
-        if constexpr (DEPTH == 16) {
-            LGC_ISSUE(8) LGC_ISSUE(9) LGC_ISSUE(10) LGC_ISSUE(11) LGC_ISSUE(12) LGC_ISSUE(13) LGC_ISSUE(14) LGC_ISSUE(15)
-        }
         LGC_STEP(0) LGC_STEP(1) LGC_STEP(2) LGC_STEP(3) LGC_STEP(4) LGC_STEP(5) LGC_STEP(6) LGC_STEP(7)
         LGC_STEP(8) LGC_STEP(9) LGC_STEP(10) LGC_STEP(11) LGC_STEP(12) LGC_STEP(13) LGC_STEP(14) LGC_STEP(15)
         LGC_STEP(16) LGC_STEP(17) LGC_STEP(18) LGC_STEP(19) LGC_STEP(20) LGC_STEP(21) LGC_STEP(22) LGC_STEP(23)
@@ -1057,7 +1042,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 8))) 
         sweep_fetch<((S) >> 1), ((S) & 1)>(cur, pk[(S) % DEPTH], vb[(S) % DEPTH]);                                     \
         const int col_ = lane_on ? (pk[(S) % DEPTH] & 0xFFFFFF) : 0xFFFFFF;                                            \
         xv[(S) % DEPTH] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(                                \
-            xsrc, __umul24(col_, xs) + xoff, 0, LGC_SWEEP_GATHER_AUX));                                                \
+            xsrc, __umul24(col_, xs) + xoff, 0, 0));                                                \
     }
 #define LGC_CONSUME(S)                                                                                                 \
     if (lds_on) {                                                                                                      \
@@ -1758,9 +1743,8 @@ int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry 
                 u = (lap & 1) ? (U - 1 - pos) : pos;
             }
             const int64_t r = u / WPBR, j = u % WPBR;
-            // bands side by side: block = (r, j / 4, band), band = block % NB (one band per XCD, all bands at once);
-            // bands one after the other: all waves of band b precede those of band b + 1 (dispatch order = time order)
-            const int64_t w = cfg.sequential ? (int64_t)b * U + u : ((r * (WPBR / 4) + j / 4) * NB + b) * 4 + (j % 4);
+            // bands side by side: block = (r, j / 4, band), band = block % NB (one band per XCD, all bands at once)
+            const int64_t w = ((r * (WPBR / 4) + j / 4) * NB + b) * 4 + (j % 4);
             wave_pieces[(size_t)w].push_back(v[k]);
         }
     }
@@ -1772,7 +1756,7 @@ int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry 
     std::vector<int64_t> wave_steps((size_t)n_waves, 0), wave_pad((size_t)n_waves, 0);
     pl.wave_npieces.assign((size_t)n_waves, 0);
     pl.piece_slot.assign((size_t)n_waves * CAP, 0);
-    const bool serpentine = cfg.round_order == 2 && !cfg.sequential;
+    const bool serpentine = cfg.round_order == 2;
     parallel_for(n_waves, [&](int64_t wlo, int64_t whi) {
         struct Item { int32_t col; float val; int32_t piece; };
         std::vector<Item> items;
@@ -1859,6 +1843,34 @@ int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry 
     return 0;
 }
 
+// Tuning switches for A/B runs, read ONCE per process (the launch paths used to call getenv per hop).
+struct Knobs {
+    bool no_fast_tiles, no_fused_apply;
+    int64_t sweep_launch_waves;
+};
+const Knobs &knobs() {
+    static const Knobs k = [] {
+        Knobs v{};
+        v.no_fast_tiles = getenv("LGCN_NO_FAST_TILES") != nullptr;
+        v.no_fused_apply = getenv("LGCN_NO_FUSED_APPLY") != nullptr;
+        const char *r = getenv("LGCN_SWEEP_LAUNCH_WAVES");
+        v.sweep_launch_waves = r ? atoll(r) : 0;
+        return v;
+    }();
+    return k;
+}
+
+// The opt-in for more than 64 KiB of dynamic LDS is per DEVICE: remember it per device ordinal.
+int allow_big_lds(const void *fn, int bytes, unsigned long long *done_mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+    if (dev >= 0 && ((*done_mask >> dev) & 1ull)) return 0;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    if (dev >= 0) *done_mask |= 1ull << dev;
+    return 0;
+}
+
 // Arguments of one tile class + whether the DPP/buffer fast path applies (see lgc_spmm_tiles).
 struct TilePrep {
     TileArgs p;
@@ -1867,15 +1879,13 @@ struct TilePrep {
 };
 
 int prepare_tiles(TilePrep &out, const int32_t *order, const int32_t *meta, const lgc_entry *slab, int32_t n_tiles, int32_t width,
-                  int32_t tiles_per_wave, int32_t parts, int64_t table_rows, const float *x, int64_t x_stride, float *y,
+                  int32_t tiles_per_wave, int64_t table_rows, const float *x, int64_t x_stride, float *y,
                   int64_t y_stride, const float *r, int64_t r_stride, float a, float b, int32_t dim) {
     if (dim < 4 || dim > 256) return LGC_E_DIM;
-    if (!order || !slab || !x || !y || n_tiles < 0 || tiles_per_wave < 1 || (parts != 1 && parts != 2) || x == y)
-        return LGC_E_INVAL;
+    if (!order || !slab || !x || !y || n_tiles < 0 || tiles_per_wave < 1 || x == y) return LGC_E_INVAL;
     if (width != 8 && width != 16 && width != 32) return LGC_E_INVAL;
     if (x_stride < dim || y_stride < dim || (r && r_stride < dim)) return LGC_E_INVAL;
     if (!aligned_to(x, 4) || !aligned_to(y, 4) || (r && !aligned_to(r, 4)) || !aligned_to(slab, 16)) return LGC_E_ALIGN;
-    if (parts == 2 && (dim % 8 != 0)) return LGC_E_INVAL;
     TileArgs p{};
     p.order = order;
     p.slab = reinterpret_cast<const u4 *>(slab);
@@ -1883,11 +1893,8 @@ int prepare_tiles(TilePrep &out, const int32_t *order, const int32_t *meta, cons
     p.x_stride = x_stride; p.y_stride = y_stride; p.r_stride = r_stride;
     p.a = a; p.b = b;
     p.n_tiles = n_tiles; p.tiles_per_wave = tiles_per_wave;
-    p.parts = parts;
-    const int pd = dim / parts;
-    p.part_col[0] = 0; p.part_dim[0] = pd;
-    p.part_col[1] = pd; p.part_dim[1] = dim - pd;
-    p.lpr = (pd + 3) / 4;
+    p.dim = dim;
+    p.lpr = (dim + 3) / 4;
     p.wt_store = (table_rows * y_stride * 4 < (int64_t(1) << 32)) ? 1 : 0;
     p.meta = meta;
     const int64_t waves = ((int64_t)n_tiles + tiles_per_wave - 1) / tiles_per_wave;
@@ -1899,16 +1906,13 @@ int prepare_tiles(TilePrep &out, const int32_t *order, const int32_t *meta, cons
         const uint32_t pad = (uint32_t)(0xFFFFFFull * (uint64_t)(stride * 4));
         return stride * 4 < (1 << 24) && table_bytes(stride) < (int64_t(1) << 32) && (int64_t)pad >= table_bytes(stride);
     };
-    out.fast = meta != nullptr && parts == 1 && ((dim >= 61 && dim <= 64) || (dim >= 68 && dim <= 128)) && table_rows > 0 &&
+    out.fast = meta != nullptr && ((dim >= 61 && dim <= 64) || (dim >= 68 && dim <= 128)) && table_rows > 0 &&
                table_rows < 0xFFFFFF &&
-               pad_is_oob(x_stride) && pad_is_oob(y_stride) && (!r || pad_is_oob(r_stride)) &&
-               getenv("LGCN_NO_FAST_TILES") == nullptr;
+               pad_is_oob(x_stride) && pad_is_oob(y_stride) && (!r || pad_is_oob(r_stride)) && !knobs().no_fast_tiles;
     if (out.fast) {
         p.x_bytes = (uint32_t)table_bytes(x_stride);
         p.y_bytes = (uint32_t)table_bytes(y_stride);
         p.r_bytes = r ? (uint32_t)table_bytes(r_stride) : 0u;
-    } else if (parts == 2) {
-        out.blocks = ((out.blocks + 3) / 4) * 8;   // XCDs 0-3 and 4-7 each get ceil(blocks / 4) * 4 workgroups
     }
     out.p = p;
     return 0;
@@ -2044,10 +2048,10 @@ int lgc_build_tiles(const int32_t *rowptr, const lgc_entry *entries, const int32
 }
 
 int lgc_spmm_tiles(const int32_t *order, const int32_t *meta, const lgc_entry *slab, int32_t n_tiles, int32_t width,
-                   int32_t tiles_per_wave, int32_t parts, int64_t table_rows, const float *x, int64_t x_stride, float *y, int64_t y_stride,
+                   int32_t tiles_per_wave, int64_t table_rows, const float *x, int64_t x_stride, float *y, int64_t y_stride,
                    const float *r, int64_t r_stride, float a, float b, int32_t dim, void *stream_) {
     TilePrep tp;
-    const int rc = prepare_tiles(tp, order, meta, slab, n_tiles, width, tiles_per_wave, parts, table_rows, x, x_stride, y, y_stride,
+    const int rc = prepare_tiles(tp, order, meta, slab, n_tiles, width, tiles_per_wave, table_rows, x, x_stride, y, y_stride,
                                  r, r_stride, a, b, dim);
     if (rc != 0) return rc;
     if (n_tiles == 0) return 0;
@@ -2154,27 +2158,16 @@ int lgc_spmm_sweep(const uint32_t *slabs, const int32_t *wave_slab_ptr, const in
 #ifdef LGC_SWEEP_TRACE   /* debug builds only (tools/sweep_trace.py): the variable carries a device address */
         if (const char *tr = getenv("LGCN_SWEEP_TRACE")) p.trace = reinterpret_cast<unsigned long long *>(strtoull(tr, nullptr, 0));
 #endif
-        static bool attr_set = false;
-        if (!attr_set) {   // more than 64 KiB of dynamic LDS needs the opt-in once per process
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               160 * 1024);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        160 * 1024);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_wide<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        160 * 1024);
-            if (e != hipSuccess) return (int)e;
-            attr_set = true;
-        }
-        const char *env_d = getenv("LGCN_SWEEP_DEPTH"), *env_r = getenv("LGCN_SWEEP_LAUNCH_WAVES");
-        const int depth = env_d ? atoi(env_d) : 8;
-        const int64_t per_launch = env_r && atoll(env_r) > 0 ? (atoll(env_r) / 4) * 4 : n_waves;
+        static unsigned long long lds_ok_sweep = 0, lds_ok_wide = 0;
+        int rc_attr = allow_big_lds(reinterpret_cast<const void *>(k_sweep<8>), 160 * 1024, &lds_ok_sweep);
+        if (rc_attr == 0) rc_attr = allow_big_lds(reinterpret_cast<const void *>(k_sweep_wide<8>), 160 * 1024, &lds_ok_wide);
+        if (rc_attr != 0) return rc_attr;
+        const int64_t req = knobs().sweep_launch_waves;
+        const int64_t per_launch = req > 0 ? std::max<int64_t>(4, (req / 4) * 4) : n_waves;
         for (int64_t w0 = 0; w0 < n_waves; w0 += per_launch) {
             p.wave_begin = (int32_t)w0;
             const unsigned blocks = (unsigned)(std::min<int64_t>(per_launch, n_waves - w0) / 4);
             if (groups == 2) hipLaunchKernelGGL(k_sweep_wide<8>, dim3(blocks), dim3(kBlock), lds, stream, p);
-            else if (depth == 16) hipLaunchKernelGGL(k_sweep<16>, dim3(blocks), dim3(kBlock), lds, stream, p);
             else hipLaunchKernelGGL(k_sweep<8>, dim3(blocks), dim3(kBlock), lds, stream, p);
             if (two_pass) {
                 SweepArgs q = p;
@@ -2208,7 +2201,7 @@ int lgc_apply(const lgc_operator *op, int64_t table_rows, const float *x, int64_
                               y_stride, r, r_stride, a, b, dim, stream);
     }
     const bool tiled = op->n_tile_classes > 0 && dim >= 4;
-    if (tiled && getenv("LGCN_NO_FUSED_APPLY") == nullptr) {
+    if (tiled && !knobs().no_fused_apply) {
         // one launch: [chunk workgroups | tile classes], then the fixed-order combine of rows cut into several chunks
         DimCfg cfg;
         if (!dim_cfg(dim, &cfg)) return LGC_E_DIM;
@@ -2229,7 +2222,7 @@ int lgc_apply(const lgc_operator *op, int64_t table_rows, const float *x, int64_
             const lgc_tile_class &tc = op->tiles[c];
             TilePrep tp;
             const int rc = prepare_tiles(tp, tc.order, tc.meta, tc.slab, tc.n_tiles, tc.width,
-                                         op->tiles_per_wave > 0 ? op->tiles_per_wave : 1, 1, table_rows, x, x_stride, y, y_stride,
+                                         op->tiles_per_wave > 0 ? op->tiles_per_wave : 1, table_rows, x, x_stride, y, y_stride,
                                          r, r_stride, a, b, dim);
             if (rc != 0) return rc;
             if (tc.n_tiles == 0) continue;
@@ -2261,7 +2254,7 @@ int lgc_apply(const lgc_operator *op, int64_t table_rows, const float *x, int64_
         for (int c = 0; c < op->n_tile_classes; ++c) {
             const lgc_tile_class &tc = op->tiles[c];
             const int rc = lgc_spmm_tiles(tc.order, tc.meta, tc.slab, tc.n_tiles, tc.width,
-                                          op->tiles_per_wave > 0 ? op->tiles_per_wave : 1, 1, table_rows, x, x_stride, y,
+                                          op->tiles_per_wave > 0 ? op->tiles_per_wave : 1, table_rows, x, x_stride, y,
                                           y_stride, r, r_stride, a, b, dim, stream);
             if (rc != 0) return rc;
         }
@@ -2271,12 +2264,14 @@ int lgc_apply(const lgc_operator *op, int64_t table_rows, const float *x, int64_
 
 int lgc_hop_exchange(const lgc_operator *item_op, const lgc_operator *user_op, int64_t table_rows, const float *x,
                      int64_t x_stride, float *y, int64_t y_stride, const float *r, int64_t r_stride, float a, float b,
-                     int32_t dim, int32_t exchange_row_begin, int32_t exchange_rows, lgc_exchange_fn exchange, void *user,
-                     void *stream) {
+                     int32_t dim, int32_t exchange_row_begin, int32_t exchange_rows, int32_t item_epilogue,
+                     lgc_exchange_fn exchange, void *user, void *stream) {
     if (!item_op || !user_op || !exchange || exchange_row_begin < 0 || exchange_rows < 0 ||
         (int64_t)exchange_row_begin + exchange_rows > table_rows)
         return LGC_E_INVAL;
-    int rc = lgc_apply(item_op, table_rows, x, x_stride, y, y_stride, r, r_stride, a, b, dim, stream);
+    // the exchanged block is SUMMED over ranks: the b * r term of the item rows may enter that sum once only
+    int rc = lgc_apply(item_op, table_rows, x, x_stride, y, y_stride, item_epilogue ? r : nullptr, item_epilogue ? r_stride : 0, a,
+                       item_epilogue ? b : 0.0f, dim, stream);
     if (rc != 0) return rc;
     rc = exchange(y + (int64_t)exchange_row_begin * y_stride, exchange_rows, y_stride, dim, stream, user);
     if (rc != 0) return rc;
@@ -2372,13 +2367,9 @@ int lgc_mask_topk(const float *scores, int64_t score_stride, const float *seen, 
                                         {k_mask_topk<true, 0>, k_mask_topk<true, 1>, k_mask_topk<true, 2>}};
     const topk_fn kern = kerns[regs][mode];
     if (lds > 16 * 1024) {    // static LDS (histogram copies, candidates) + the bitmask can pass the 64 KiB default
-        static bool attr_set[2] = {false, false};
-        if (!attr_set[regs]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
-            if (e != hipSuccess) return (int)e;
-            attr_set[regs] = true;
-        }
+        static unsigned long long lds_ok_topk[2][3] = {};
+        const int rc_attr = allow_big_lds(reinterpret_cast<const void *>(kern), 120 * 1024, &lds_ok_topk[regs][mode]);
+        if (rc_attr != 0) return rc_attr;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)n_rows), dim3(kTopkBlock), lds, as_stream(stream_), scores, score_stride, seen,
                        seen_stride, list_ptr, list_items, list_rows, n_cols, k, out_index, out_value);

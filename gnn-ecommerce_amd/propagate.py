@@ -76,7 +76,6 @@ def horner_hops(op: Operator, x0: Tensor, alphas: Sequence[float]) -> Tensor:
 
 USE_BIPARTITE = os.environ.get("LGCN_BIPARTITE", "1") == "1"
 
-
 class _HopSpan:
     """Events around one layer's launches (both halves), appended to HOP_EVENT_LOG when bench.py asks."""
 

@@ -121,16 +121,13 @@ int lgc_build_csr(const int64_t *edge_index, const float *edge_weight,
  *            are allowed), or NULL.  With meta, a 61..64- or 68..128-wide table and tables below 4 GiB the kernel takes
  *            the path without divergent control flow (DPP broadcasts, buffer addressing); otherwise a generic one.
  *   width    8, 16 or 32 entries per row
- *   parts    1, or 2 (dim a multiple of 8; meant for dim*4 a multiple of 256 bytes, generic path only): the two
- *            column halves of every row are computed by workgroups on different XCDs, halving the bytes of the
- *            gathered table each XCD's L2 has to hold
  *   y[row] = a * sum_k val_k * x[col_k] + b * r[row]   (r may be NULL)
  */
 int lgc_build_tiles(const int32_t *rowptr, const lgc_entry *entries, const int32_t *order, int64_t n_slots,
                     int32_t width, lgc_entry *slab, void *stream);
 
 int lgc_spmm_tiles(const int32_t *order, const int32_t *meta, const lgc_entry *slab, int32_t n_tiles, int32_t width,
-                   int32_t tiles_per_wave, int32_t parts, int64_t table_rows, const float *x, int64_t x_stride,
+                   int32_t tiles_per_wave, int64_t table_rows, const float *x, int64_t x_stride,
                    float *y, int64_t y_stride, const float *r, int64_t r_stride, float a, float b, int32_t dim,
                    void *stream);
 
@@ -189,10 +186,6 @@ typedef struct lgc_sweep_cfg {
     int32_t piece_cap;             /* 64: longest run of one row's entries inside one wavefront's list; raised in
                                       steps of 16 (up to 4x) while that saves a whole round                */
     int32_t lookahead;             /* 64: how far the step builder looks for an entry of another piece  */
-    int32_t sequential;            /* 0: band b runs on XCD b, all bands at once (several rounds when the pieces of a band
-                                      exceed one XCD's LDS); 1: the bands run one after the other on the whole chip
-                                      (waves_per_band_round = all wavefronts of the chip, normally one round): a band then
-                                      fits the Infinity Cache, so re-fetches by other XCDs are on-die                    */
     int32_t groups;                /* entries per step = table rows a wavefront gathers per instruction: 4 (or 0) for tables
                                       of 61..64 columns (a 16-lane group per row, 1 KiB slabs), 2 for 68..96 columns (two
                                       DPP rows per row, 512-byte slabs)                                                   */
@@ -228,7 +221,6 @@ int lgc_spmm_sweep(const uint32_t *slabs, const int32_t *wave_slab_ptr, const in
                    const int32_t *piece_slot, int64_t n_waves, int32_t row_cap, int32_t groups, const lgc_multi_row *multi,
                    int32_t n_rows, const lgc_multi_row *multi_wide, int32_t n_wide, float *partials, int64_t table_rows, const float *x, int64_t x_stride, float *y,
                    int64_t y_stride, const float *r, int64_t r_stride, float a, float b, int32_t dim, void *stream);
-
 /* ---------------------------------------------------------------------------------------
  * One operator half as a single argument, and the per-hop exchange hook.
  *
@@ -245,6 +237,9 @@ int lgc_spmm_sweep(const uint32_t *slabs, const int32_t *wave_slab_ptr, const in
  * y_stride floats) in stream order -- e.g. ncclAllReduce(block, block, rows * row_stride, ncclFloat, ncclSum, comm,
  * stream) when y_stride == dim -- and return 0; it is the only place where the library needs the host's
  * communicator, which it never sees.  A non-zero return aborts the hop and is handed back.
+ * `item_epilogue`: the exchanged block is a SUM over ranks, so the b * r term of the item rows may enter it once only:
+ * pass 1 on exactly one rank (rank 0) and 0 on the others -- with the same r and b everywhere; the user step applies
+ * the epilogue of this rank's own user rows on every rank.
  */
 typedef struct lgc_tile_class {
     const int32_t   *order;      /* device, [n_tiles * R]            */
@@ -281,8 +276,8 @@ typedef int (*lgc_exchange_fn)(float *block, int64_t rows, int64_t row_stride, i
 
 int lgc_hop_exchange(const lgc_operator *item_op, const lgc_operator *user_op, int64_t table_rows, const float *x,
                      int64_t x_stride, float *y, int64_t y_stride, const float *r, int64_t r_stride, float a, float b,
-                     int32_t dim, int32_t exchange_row_begin, int32_t exchange_rows, lgc_exchange_fn exchange,
-                     void *user, void *stream);
+                     int32_t dim, int32_t exchange_row_begin, int32_t exchange_rows, int32_t item_epilogue,
+                     lgc_exchange_fn exchange, void *user, void *stream);
 
 /* Fixed-order sum of runs -- how the sparse gradient of a scoring step (src/lightgcn.py:123-125 scores 2B pairs; what
  * autograd's index_select backward does with float atomics at src/train_lightgcn.py:146) is accumulated deterministically:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes around ANY command (each pass its own rocprofv3 run with --kernel-trace + --pmc only, as
 # MI355X_MICROARCH.md prescribes; a pass whose counter set the hardware refuses is reported and skipped).
-#     bash profiles/pmc_passes.sh <tag> python3 tools/run_user_half.py tiles cold 2 2
+#     bash profiles/pmc_passes.sh <tag> python3 tools/run_step.py user
 # Output: gpurun_out/pmc_<tag>/summary.txt (+ deep.json): per kernel, mean of every counter and of the duration.
 # The TA / TCP stall counters are split over passes of at most two TA counters: four in one pass exceeded the
 # block's capacity (rocprofiler error 38, round 1 gpurun_out/deep_a/p4.log).

@@ -105,7 +105,7 @@ int main(void) {
     CHECK_HIP(hipMemcpy(d_order, order, sizeof(int32_t) * n_short, hipMemcpyHostToDevice));
     CHECK_LGC(lgc_build_tiles(d_rowptr, d_entries, d_order, n_short, 8, d_slab, stream));
     CHECK_HIP(hipMemsetAsync(d_y, 0xFF, sizeof(float) * n * dim, stream));
-    CHECK_LGC(lgc_spmm_tiles(d_order, NULL, d_slab, (int32_t)(n_short / 16), 8, 1, 1, n, d_x, dim, d_y, dim, NULL, 0, 1.0f, 0.0f, dim, stream));
+    CHECK_LGC(lgc_spmm_tiles(d_order, NULL, d_slab, (int32_t)(n_short / 16), 8, 1, n, d_x, dim, d_y, dim, NULL, 0, 1.0f, 0.0f, dim, stream));
     CHECK_HIP(hipMemcpyAsync(got, d_y, sizeof(float) * n * dim, hipMemcpyDeviceToHost, stream));
     CHECK_HIP(hipStreamSynchronize(stream));
     double err_tiles = 0.0;

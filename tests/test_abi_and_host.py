@@ -73,11 +73,11 @@ def test_argument_errors_are_reported_before_any_launch():
     assert lib.lgc_spmm(one, one, 0, 4, 32, None, 3, None, 0, None, 8, one, 64, ctypes.c_void_p(32), 64, None, 0,
                         1.0, 0.0, 64, None) == -1                                       # chunks missing
     two = ctypes.c_void_p(32)
-    tiles = lambda **kw: lib.lgc_spmm_tiles(one, one, one, kw.get("n", 4), kw.get("w", 8), kw.get("tpw", 1), kw.get("parts", 1),
+    tiles = lambda **kw: lib.lgc_spmm_tiles(one, one, one, kw.get("n", 4), kw.get("w", 8), kw.get("tpw", 1),
                                             100, one, kw.get("xs", 64), kw.get("y", two), 64, None, 0, 1.0, 0.0,
                                             kw.get("dim", 64), None)
     assert tiles(dim=300) == -2 and tiles(dim=3) == -2                                    # LGC_E_DIM (tiles need >= 4)
-    assert tiles(w=12) == -1 and tiles(tpw=0) == -1 and tiles(parts=3) == -1 and tiles(y=one) == -1
+    assert tiles(w=12) == -1 and tiles(tpw=0) == -1 and tiles(y=one) == -1
     assert tiles(xs=32) == -1 and tiles(n=-1) == -1
     assert tiles(n=0) == 0                                                                # nothing to do: no launch
     assert lib.lgc_build_tiles(one, one, one, 15, 8, one, None) == -1                     # not whole tiles
@@ -411,7 +411,7 @@ def _decode_sweep(dims, arr, row_cap):
 @pytest.mark.parametrize("cfg", [dict(n_bands=8, waves_per_band_round=16, row_cap=39, piece_cap=64, lookahead=32),
                                  dict(n_bands=3, waves_per_band_round=4, row_cap=7, piece_cap=5, lookahead=4),
                                  dict(n_bands=1, waves_per_band_round=8, row_cap=200, piece_cap=1000, lookahead=64),
-                                 dict(n_bands=4, waves_per_band_round=64, row_cap=78, piece_cap=64, lookahead=64, sequential=1),
+                                 dict(n_bands=4, waves_per_band_round=64, row_cap=78, piece_cap=64, lookahead=64),
                                  dict(n_bands=8, waves_per_band_round=16, row_cap=51, piece_cap=64, lookahead=64, groups=2),
                                  dict(n_bands=8, waves_per_band_round=4, row_cap=3, piece_cap=64, lookahead=32, round_order=1),
                                  dict(n_bands=3, waves_per_band_round=4, row_cap=7, piece_cap=5, lookahead=4, round_order=1),
@@ -483,7 +483,7 @@ def test_sweep_plan_on_random_small_operators():
         cols = [draw(st.lists(st.integers(0, n_cols - 1), min_size=l, max_size=l)) for l in lens]
         cfg = dict(n_bands=draw(st.sampled_from([1, 2, 3, 8])), waves_per_band_round=draw(st.sampled_from([4, 8])),
                    row_cap=draw(st.sampled_from([1, 2, 5, 78])), piece_cap=draw(st.sampled_from([1, 3, 64])),
-                   lookahead=draw(st.sampled_from([4, 64])), sequential=draw(st.sampled_from([0, 1])),
+                   lookahead=draw(st.sampled_from([4, 64])),
                    groups=draw(st.sampled_from([2, 4])), round_order=draw(st.sampled_from([0, 1, 2])))
         return n_cols, cols, cfg
 
@@ -524,7 +524,7 @@ def test_sweep_plan_argument_errors():
 
     def create(lo=0, hi=8, **kw):
         cfg = _native.SweepCfg(**{**dict(n_bands=8, waves_per_band_round=16, row_cap=39, piece_cap=64, lookahead=32,
-                                         sequential=0, groups=4), **kw})
+                                         groups=4), **kw})
         h = lib.lgc_sweep_plan_create(rowptr.data_ptr(), entries.data_ptr(), 0, 2, lo, hi, ct.byref(cfg), ct.byref(code))
         if h:
             lib.lgc_sweep_plan_free(h)

