@@ -91,6 +91,8 @@ SIGNATURES = {
                                 c_void_p]),
     "lgc_seed_pull": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p,
                               c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int32, c_void_p]),
+    "lgc_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
+                              c_float, c_void_p]),
     "lgc_lincomb": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p]),
     "lgc_mask_topk": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
                               c_void_p, c_void_p, c_void_p]),

@@ -708,7 +708,9 @@ __device__ __forceinline__ void tiles_body_dpp(const TileArgs &p, const int64_t 
                 acc.v[3] = __fadd_rn(acc.v[3], __fmul_rn(p.b, rv.w));
             }
             const f4 o = {acc.v[0], acc.v[1], acc.v[2], acc.v[3]};
-            // sc1 write-through: the output row is not read again in this launch (the host made sure of < 4 GiB)
+            // the output row is not read again in this launch (the host made sure of < 4 GiB): cache policy kTileStoreAux.
+            // Holding a tile's four output rows back until its last batch, or keeping a batch's eight gathers in flight
+            // together, changes nothing (539.7 / 539.6 / 539.5 us per hop, profiles/r03h_defer_stores_batch8.txt)
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o), ysrc, __umul24(row24, ys) + xoff, 0, kTileStoreAux);
         }
     }
@@ -1148,20 +1150,20 @@ __global__ __launch_bounds__(kBlock) void k_sweep_combine(SpmmArgs p, const lgc_
     acc.zero();
     rv.zero();
     if (p.r != nullptr) rv = load_row<VEC>(p.r + (int64_t)mr.row * p.r_stride + c0);
-    int32_t s = mr.slot_begin;
-    for (; s + 4 <= mr.slot_end; s += 4) {
-        Acc<VEC> t0 = load_row<VEC>(pb + (int64_t)s * p.dim);
-        Acc<VEC> t1 = load_row<VEC>(pb + (int64_t)(s + 1) * p.dim);
-        Acc<VEC> t2 = load_row<VEC>(pb + (int64_t)(s + 2) * p.dim);
-        Acc<VEC> t3 = load_row<VEC>(pb + (int64_t)(s + 3) * p.dim);
+    // a row has one slot per band it touches (8 here) plus the cuts of long pieces: eight loads in flight, slots past
+    // the row's end read as +0 (adding +0 never changes the sum: it cannot be -0 after its first add), so a row of up to
+    // eight slots costs one memory round trip -- it used to be 4 + 4 and then one load at a time for the rest
+    for (int32_t s = mr.slot_begin; s < mr.slot_end; s += 8) {
+        Acc<VEC> t[8];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i)
-            acc.v[i] = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(acc.v[i], t0.v[i]), t1.v[i]), t2.v[i]), t3.v[i]);
-    }
-    for (; s < mr.slot_end; ++s) {
-        Acc<VEC> t0 = load_row<VEC>(pb + (int64_t)s * p.dim);
+        for (int j = 0; j < 8; ++j) {
+            t[j].zero();
+            if (s + j < mr.slot_end) t[j] = load_row<VEC>(pb + (int64_t)(s + j) * p.dim);
+        }
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) acc.v[i] = __fadd_rn(acc.v[i], t0.v[i]);
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc.v[i] = __fadd_rn(acc.v[i], t[j].v[i]);
     }
     finish_row<VEC, SpmmArgs>(p, mr.row, c0, acc, rv);
 }
@@ -1211,6 +1213,53 @@ __global__ void k_lincomb(float *__restrict__ y, int64_t y_stride, LincombArgs a
         for (int t = 1; t < a.n_terms; ++t) v = __fadd_rn(v, __fmul_rn(a.coef[t], a.src[t][row * a.stride[t] + c]));
         y[row * y_stride + c] = v;
     }
+}
+
+// ----------------------------------------------------------------------------------------
+// Dense Adam step over the embedding table (the caller's optimizer.step(), src/train_lightgcn.py:58,147)
+// ----------------------------------------------------------------------------------------
+// One pass: w, g, m, v read once, w, m, v written once (7 x 434 MB at 1.7 M x 64): torch.optim.Adam's arithmetic for
+// amsgrad=False, weight_decay=0, maximize=False --
+//   m <- m + (g - m) (1 - beta1);  v <- beta2 v + (1 - beta2) g g;  w <- w - (lr / bc1) m / (sqrt(v) / sqrt(bc2) + eps)
+// with bc1 = 1 - beta1^t, bc2 = 1 - beta2^t computed by the host in double and handed over as step_size, bc2_sqrt.
+// (1 - beta1) and (1 - beta2) come from the host, rounded from double like torch's scalars: 1.0f - 0.999f is 4.7e-5 off.
+__global__ __launch_bounds__(kBlock) void k_adam(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m,
+                                                float *__restrict__ v, int64_t n4, int64_t n, float beta2, float omb1, float omb2,
+                                                float eps, float step_size, float bc2_sqrt) {
+    auto one = [&](float &wi, float gi, float &mi, float &vi) {
+        mi = mi + (gi - mi) * omb1;
+        vi = beta2 * vi + omb2 * gi * gi;
+        wi = wi - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    };
+    constexpr int U = 2;                      // float4s per thread and array: 8 loads in flight per thread
+    const int64_t base = ((int64_t)blockIdx.x * blockDim.x) * U + threadIdx.x;
+    f4 w4[U], g4[U], m4[U], v4[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t i = base + (int64_t)u * blockDim.x;
+        if (i < n4) {
+            w4[u] = reinterpret_cast<f4 *>(w)[i];
+            g4[u] = reinterpret_cast<const f4 *>(g)[i];
+            m4[u] = reinterpret_cast<f4 *>(m)[i];
+            v4[u] = reinterpret_cast<f4 *>(v)[i];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t i = base + (int64_t)u * blockDim.x;
+        if (i < n4) {
+            float wv[4] = {w4[u].x, w4[u].y, w4[u].z, w4[u].w}, gv[4] = {g4[u].x, g4[u].y, g4[u].z, g4[u].w};
+            float mv[4] = {m4[u].x, m4[u].y, m4[u].z, m4[u].w}, vv[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) one(wv[j], gv[j], mv[j], vv[j]);
+            reinterpret_cast<f4 *>(w)[i] = f4{wv[0], wv[1], wv[2], wv[3]};
+            reinterpret_cast<f4 *>(m)[i] = f4{mv[0], mv[1], mv[2], mv[3]};
+            reinterpret_cast<f4 *>(v)[i] = f4{vv[0], vv[1], vv[2], vv[3]};
+        }
+    }
+    // tail (n not a multiple of 4): the first threads of block 0
+    const int64_t t = n4 * 4 + threadIdx.x;
+    if (blockIdx.x == 0 && t < n) one(w[t], g[t], m[t], v[t]);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -2336,6 +2385,19 @@ int lgc_lincomb(float *y, int64_t y_stride, const float *const *src, const int64
     if (n_rows == 0) return 0;
     int blocks = (int)std::min<int64_t>(ceil_div(n_rows * dim, kBlock), 256 * 8);
     hipLaunchKernelGGL(k_lincomb, dim3(blocks), dim3(kBlock), 0, as_stream(stream_), y, y_stride, a, n_rows, dim);
+    return (int)hipGetLastError();
+}
+
+int lgc_adam_step(float *w, const float *g, float *m, float *v, int64_t n, float one_minus_beta1, float beta2,
+                  float one_minus_beta2, float eps, float step_size, float bias_correction2_sqrt, void *stream_) {
+    if (!w || !g || !m || !v || n < 0 || !(bias_correction2_sqrt > 0.0f)) return LGC_E_INVAL;
+    if (!aligned_to(w, 16) || !aligned_to(g, 16) || !aligned_to(m, 16) || !aligned_to(v, 16)) return LGC_E_ALIGN;
+    if (n == 0) return 0;
+    const int64_t n4 = n / 4;
+    const int64_t blocks = std::max<int64_t>(ceil_div(n4, (int64_t)kBlock * 2), 1);
+    if (blocks >= INT32_MAX) return LGC_E_RANGE;
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream_), w, g, m, v, n4, n, beta2,
+                       one_minus_beta1, one_minus_beta2, eps, step_size, bias_correction2_sqrt);
     return (int)hipGetLastError();
 }
 

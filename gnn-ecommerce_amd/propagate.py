@@ -359,8 +359,10 @@ def seeded_transpose_sum(graph: PropGraph, rows: Tensor, vals: Tensor, alphas: S
         with _HopSpan():
             nxt = scratch_table(g_tab)
             if layer == 1:
-                _seed_pull(item_t, flag, slot, gu, nxt)                         # x_1[items] from the seed users
-                flag[fidx] = 0
+                try:
+                    _seed_pull(item_t, flag, slot, gu, nxt)                     # x_1[items] from the seed users
+                finally:
+                    flag[fidx] = 0                                              # the flags are all zero between steps
             else:
                 item_t.apply(tables[-1], nxt)
             if layer < k:

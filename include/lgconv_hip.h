@@ -308,6 +308,18 @@ int lgc_lincomb(float *y, int64_t y_stride, const float *const *src, const int64
                 const float *coef, int32_t n_terms, int64_t n_rows, int32_t dim, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Dense Adam step over a contiguous fp32 table in ONE pass (w, g, m, v read once; w, m, v written once): what
+ * `optimizer.step()` of `torch.optim.Adam(model.parameters(), lr)` does at src/train_lightgcn.py:58,147 (amsgrad off, no
+ * weight decay):  m <- m + (g - m)(1 - beta1);  v <- beta2 v + (1 - beta2) g^2;
+ *                 w <- w - step_size * m / (sqrt(v) / bias_correction2_sqrt + eps)
+ * with step_size = lr / (1 - beta1^t) and bias_correction2_sqrt = sqrt(1 - beta2^t) computed by the host (t = step
+ * count), and (1 - beta1), (1 - beta2) handed over as the host rounds them from double, like torch's own scalars
+ * (1.0f - 0.999f is 4.7e-5 away from 0.001f).  All four pointers 16-byte aligned, n elements each.
+ * ------------------------------------------------------------------------------------- */
+int lgc_adam_step(float *w, const float *g, float *m, float *v, int64_t n, float one_minus_beta1, float beta2,
+                  float one_minus_beta2, float eps, float step_size, float bias_correction2_sqrt, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Pair scoring: scores[m] = <emb[idx0[m]], emb[idx1[m]]>.
  * Replaces src/lightgcn.py:123-125.  idx are the rows of edge_label_index
  * (src/utils_v2.py:184-190), int64.  Out-of-range pairs score NaN and set LGC_ST_INDEX_OOB.

@@ -19,7 +19,11 @@ for name, dst in ((f"gpurun_out/bench_{tag}.json", f"profiles/{tag}_bench.json")
     if os.path.isfile(name):
         open(dst, "w").write(open(name).read().strip().splitlines()[-1] + "\n")
 t = json.load(open("profiles/traffic.json"))
-t.update(source=f"profiles/{tag}_pmc_summary.json", kernel_source_sha256=h, cosmetics_d64=d["traffic_json"]["hbm_bytes_per_hop"])
+import datetime
+stamp = datetime.datetime.fromtimestamp(os.path.getmtime(f"{src}/summary.json")).strftime("%Y-%m-%d %H:%M")
+t.update(source=f"profiles/{tag}_pmc_summary.json", kernel_source_sha256=h, cosmetics_d64=d["traffic_json"]["hbm_bytes_per_hop"],
+         measured_on=f"rocprofv3 PMC passes of profiles/collect.sh, run '{tag}' on a gpurun MI355X box (summary written {stamp}); "
+                     "not the process that prints the bench line")
 json.dump(t, open("profiles/traffic.json", "w"), indent=1)
 d90 = f"gpurun_out/prof_{tag}_d90"
 if os.path.isfile(f"{d90}/summary.json"):          # the D=90 / K=5 configuration, collected with HOPS=40

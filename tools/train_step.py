@@ -14,7 +14,8 @@ ap.add_argument("--steps", type=int, default=10); ap.add_argument("--batch", typ
 ap.add_argument("--sampler", choices=["uniform", "device", "python"], default="uniform",
                 help="uniform: seeded uniform triples (SURVEY 8d); device: TripleSampler (batch_loader contract on "
                      "the GPU); python: the oracle restatement of the reference's batch_loader on the host")
-ap.add_argument("--adam", choices=["default", "fused"], default="default", help="torch.optim.Adam(fused=...)")
+ap.add_argument("--adam", choices=["default", "fused", "hip"], default="default",
+                help="torch.optim.Adam(fused=False|True), or hip: gnn_ecommerce_amd.optim.Adam (one pass, lgc_adam_step)")
 ap.add_argument("--reg", choices=["caller", "routed"], default="routed",
                 help="caller: upstream's regularization_loss on plain torch ops (three dense [N, D] gradients); routed: "
                      "gnn_ecommerce_amd.regularization_loss (same value, gradient added inside the scoring node)")
@@ -27,7 +28,11 @@ dev = torch.device("cuda:0")
 g = synth.make_bipartite(**synth.CONFIG_COSMETICS, seed=0)
 ei, ew = g.coo(dev)
 model = lg.LightGCN(g.num_nodes, args.dim, args.layers).to(dev)
-opt = torch.optim.Adam(model.parameters(), 0.005, fused=(args.adam == 'fused'))
+if args.adam == "hip":
+    from gnn_ecommerce_amd.optim import Adam as HipAdam
+    opt = HipAdam(model.parameters(), 0.005)
+else:
+    opt = torch.optim.Adam(model.parameters(), 0.005, fused=(args.adam == 'fused'))
 gen = torch.Generator().manual_seed(0)
 purchase = g.weight == 1.0                      # positives = purchases, as pos_item_list (src/utils_v2.py:64-73)
 pu, pi = g.user[purchase], g.item[purchase] + g.n_users
