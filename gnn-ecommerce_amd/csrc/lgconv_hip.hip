@@ -834,6 +834,12 @@ __global__ __launch_bounds__(kBlock) void k_rows_tile_dpp(TileArgs p) {
 //     entries (col = 0xFFFFFF, out of range: zeros) update a dummy LDS row;
 //   * at the end a wave writes its pieces to their partial slots (contiguous per output row, band-major) and
 //     k_spmm_combine adds a row's slots in that fixed order: deterministic, no float atomics.
+// Gathers a wavefront of the row sweep keeps in flight: 8 slots, of which the compiler fills seven under the 64-register
+// budget.  Both directions lose: four in flight 48 % L2 hits and 247 us, a full eight 41 % and 249-263 us, sixteen 301 us,
+// against 52-53 % and 241-245 us (profiles/r03a, r03j, r03k) -- how far the 256 wavefronts of a band drift apart, and with
+// it the L2 hit rate, depends on it more than the memory-level parallelism does.
+constexpr int kSweepDepth = 8;
+
 struct SweepArgs {
     const u4 *slabs;               // [n_slabs * 64]
     const int32_t *wave_slab_ptr;  // [n_waves + 1]
@@ -848,6 +854,26 @@ struct SweepArgs {
     int32_t pstride, pcol;         // partial rows are pstride floats, this launch fills columns pcol .. pcol + dim
 };
 
+// A wavefront's piece -> partial-slot table, read ONCE at its start (lane i keeps pieces i, 64 + i, ...) so that the
+// write-out at its end issues its stores back to back: fetched inside that loop, every iteration waited for a dependent
+// load -- and, vmcnt retiring in order, for the previous iteration's store to HBM.
+struct PieceSlots {
+    int s[4];                                   // row_cap <= 254
+    __device__ __forceinline__ void load(const int32_t *slots, int npieces, int lane) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] = (j * 64 + lane < npieces) ? slots[j * 64 + lane] : 0;
+    }
+    __device__ __forceinline__ int at(int pc) const {   // pc may differ between lanes
+        int v = __shfl(s[0], pc & 63);
+#pragma unroll
+        for (int j = 1; j < 4; ++j) {
+            const int o = __shfl(s[j], pc & 63);
+            v = (pc >> 6) == j ? o : v;
+        }
+        return v;
+    }
+};
+
 template <int Q, int HALF>
 __device__ __forceinline__ void sweep_fetch(const u4 &cur, int &packed, int &valbits) {
     packed = bcast16<Q>((int)(HALF ? cur.z : cur.x));
@@ -855,6 +881,9 @@ __device__ __forceinline__ void sweep_fetch(const u4 &cur, int &packed, int &val
 }
 
 template <int DEPTH>
+// The register budget stays at 64 although the 158 KiB of accumulators allow only two wavefronts per SIMD: with 128 the
+// compiler keeps a full eight gathers in flight instead of seven, the wavefronts of a band drift apart and the L2 hit rate
+// falls from 53 to 41 % (item step 282 vs 266 us, profiles/r03j_*) -- the same effect as the continuous pipeline of section 8.
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 8))) void k_sweep(SweepArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & (kWave - 1);
@@ -876,6 +905,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 8))) 
     int slab = p.wave_slab_ptr[w];
     const int slab_end = p.wave_slab_ptr[w + 1];
     if (slab >= slab_end) return;
+    PieceSlots piece_slots;
+    piece_slots.load(p.piece_slot + (int64_t)w * p.row_cap, npieces, lane);
     u4 nxt = __builtin_nontemporal_load(p.slabs + (int64_t)slab * kWave + lane);
 #ifdef LGC_SWEEP_TRACE
     int tk = 0;
@@ -906,7 +937,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 8))) 
 #define LGC_STEP(S)                                                                                                    \
     LGC_CONSUME(S)                                                                                                     \
     if constexpr ((S) + DEPTH < 32) LGC_ISSUE((S) + DEPTH)
-        LGC_ISSUE(0) LGC_ISSUE(1) LGC_ISSUE(2) LGC_ISSUE(3) LGC_ISSUE(4) LGC_ISSUE(5) LGC_ISSUE(6) LGC_ISSUE(7)
+        LGC_ISSUE(0) LGC_ISSUE(1) LGC_ISSUE(2) LGC_ISSUE(3)
+        if constexpr (DEPTH >= 8) { LGC_ISSUE(4) LGC_ISSUE(5) LGC_ISSUE(6) LGC_ISSUE(7) }
         LGC_STEP(0) LGC_STEP(1) LGC_STEP(2) LGC_STEP(3) LGC_STEP(4) LGC_STEP(5) LGC_STEP(6) LGC_STEP(7)
         LGC_STEP(8) LGC_STEP(9) LGC_STEP(10) LGC_STEP(11) LGC_STEP(12) LGC_STEP(13) LGC_STEP(14) LGC_STEP(15)
         LGC_STEP(16) LGC_STEP(17) LGC_STEP(18) LGC_STEP(19) LGC_STEP(20) LGC_STEP(21) LGC_STEP(22) LGC_STEP(23)
@@ -921,14 +953,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 8))) 
 #ifdef LGC_SWEEP_TRACE
     if (p.trace && lane == 0) p.trace[(int64_t)w * 16 + 15] = __builtin_amdgcn_s_memrealtime();   // end of the last slab
 #endif
-    // write my pieces to their partial slots: lane group g takes pieces g, g + 4, ...
-    const int32_t *slots = p.piece_slot + (int64_t)w * p.row_cap;
-    for (int pc = g; pc < npieces; pc += 4) {
-        const f4 a = *reinterpret_cast<const f4 *>(mine + pc * 64);
-        Acc<4> o;
-        o.v[0] = a.x; o.v[1] = a.y; o.v[2] = a.z; o.v[3] = a.w;
-        const f4 t = {o.v[0], o.v[1], o.v[2], o.v[3]};
-        __builtin_nontemporal_store(t, reinterpret_cast<f4u *>(p.partials + (int64_t)slots[pc] * p.pstride + p.pcol + c0));
+    // write my pieces to their partial slots: lane group g takes pieces g, g + 4, ... (every lane runs the shuffles)
+    for (int pc0 = 0; pc0 < npieces; pc0 += 4) {
+        const int pc = pc0 + g;
+        const int slot = piece_slots.at(min(pc, npieces - 1));
+        if (pc < npieces) {
+            const f4 a = *reinterpret_cast<const f4 *>(mine + pc * 64);
+            __builtin_nontemporal_store(a, reinterpret_cast<f4u *>(p.partials + (int64_t)slot * p.pstride + p.pcol + c0));
+        }
     }
 }
 
@@ -1031,6 +1063,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 8))) 
     int slab = p.wave_slab_ptr[w];
     const int slab_end = p.wave_slab_ptr[w + 1];
     if (slab >= slab_end) return;
+    PieceSlots piece_slots;
+    piece_slots.load(p.piece_slot + (int64_t)w * p.row_cap, npieces, lane);
     // a 512-byte slab = 32 pieces; lanes of pair g read pieces 16 g + l (both of its DPP rows the same ones)
     const int piece_lane = pair * 16 + l;
     u4 nxt = __builtin_nontemporal_load(p.slabs + (int64_t)slab * 32 + piece_lane);
@@ -1068,12 +1102,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 8))) 
 #undef LGC_CONSUME
 #undef LGC_ISSUE
     }
-    // write my pieces to their partial slots: pair g takes pieces g, g + 2, ...
-    const int32_t *slots = p.piece_slot + (int64_t)w * p.row_cap;
-    for (int pc = pair; pc < npieces; pc += 2) {
-        if (lane_on) {
+    // write my pieces to their partial slots: pair g takes pieces g, g + 2, ... (every lane runs the shuffles)
+    for (int pc0 = 0; pc0 < npieces; pc0 += 2) {
+        const int pc = pc0 + pair;
+        const int slot = piece_slots.at(min(pc, npieces - 1));
+        if (pc < npieces && lane_on) {
             const f4 a = *reinterpret_cast<const f4 *>(mine + pc * kWideRow);
-            __builtin_nontemporal_store(a, reinterpret_cast<f4u *>(p.partials + (int64_t)slots[pc] * p.dim + c0));
+            __builtin_nontemporal_store(a, reinterpret_cast<f4u *>(p.partials + (int64_t)slot * p.dim + c0));
         }
     }
 }
@@ -2208,7 +2243,7 @@ int lgc_spmm_sweep(const uint32_t *slabs, const int32_t *wave_slab_ptr, const in
         if (const char *tr = getenv("LGCN_SWEEP_TRACE")) p.trace = reinterpret_cast<unsigned long long *>(strtoull(tr, nullptr, 0));
 #endif
         static unsigned long long lds_ok_sweep = 0, lds_ok_wide = 0;
-        int rc_attr = allow_big_lds(reinterpret_cast<const void *>(k_sweep<8>), 160 * 1024, &lds_ok_sweep);
+        int rc_attr = allow_big_lds(reinterpret_cast<const void *>(k_sweep<kSweepDepth>), 160 * 1024, &lds_ok_sweep);
         if (rc_attr == 0) rc_attr = allow_big_lds(reinterpret_cast<const void *>(k_sweep_wide<8>), 160 * 1024, &lds_ok_wide);
         if (rc_attr != 0) return rc_attr;
         const int64_t req = knobs().sweep_launch_waves;
@@ -2217,14 +2252,14 @@ int lgc_spmm_sweep(const uint32_t *slabs, const int32_t *wave_slab_ptr, const in
             p.wave_begin = (int32_t)w0;
             const unsigned blocks = (unsigned)(std::min<int64_t>(per_launch, n_waves - w0) / 4);
             if (groups == 2) hipLaunchKernelGGL(k_sweep_wide<8>, dim3(blocks), dim3(kBlock), lds, stream, p);
-            else hipLaunchKernelGGL(k_sweep<8>, dim3(blocks), dim3(kBlock), lds, stream, p);
+            else hipLaunchKernelGGL(k_sweep<kSweepDepth>, dim3(blocks), dim3(kBlock), lds, stream, p);
             if (two_pass) {
                 SweepArgs q = p;
                 q.x = x + 64;
                 q.dim = dim - 64;
                 q.x_bytes = (uint32_t)(((table_rows - 1) * x_stride + (dim - 64)) * 4);
                 q.pcol = 64;
-                hipLaunchKernelGGL(k_sweep<8>, dim3(blocks), dim3(kBlock), lds, stream, q);
+                hipLaunchKernelGGL(k_sweep<kSweepDepth>, dim3(blocks), dim3(kBlock), lds, stream, q);
             }
         }
     }

@@ -330,6 +330,29 @@ def test_cold_order_puts_rows_sharing_a_rare_column_next_to_each_other():
         assert len(set(second[t].tolist())) == 4
 
 
+def test_argument_errors_of_the_round3_entry_points():
+    """lgc_segment_sum, lgc_seed_pull, lgc_adam_step, lgc_hop_exchange: bad arguments are refused before any launch."""
+    lib = _native.load()
+    one, two = ctypes.c_void_p(256), ctypes.c_void_p(512)
+    seg = lambda **kw: lib.lgc_segment_sum(kw.get("key", one), one, one, kw.get("n", 8), 1.0, kw.get("y", two), kw.get("ys", 64),
+                                           100, kw.get("dim", 64), 0, None)
+    assert seg(y=None) == -1 and seg(n=-1) == -1 and seg(dim=0) == -1 and seg(dim=300) == -1 and seg(ys=32) == -1
+    assert seg(key=None) == -1 and seg(n=0) == 0                                  # nothing to do is not an error
+    pull = lambda **kw: lib.lgc_seed_pull(one, one, 0, 4, 32, None, kw.get("n_chunks", 0), None, 0, None, kw.get("flag", one),
+                                          one, one, kw.get("ss", 64), 8, kw.get("y", two), 64, kw.get("dim", 64), None)
+    assert pull(dim=300) == -2 and pull(flag=None) == -1 and pull(ss=32) == -1 and pull(n_chunks=3) == -1
+    assert pull(y=ctypes.c_void_p(514)) == -5
+    adam = lambda **kw: lib.lgc_adam_step(kw.get("w", one), one, one, one, kw.get("n", 64), 0.1, 0.999, 0.001, 1e-8, 0.005,
+                                          kw.get("bc2", 0.03), None)
+    assert adam(w=None) == -1 and adam(n=-1) == -1 and adam(bc2=0.0) == -1 and adam(w=ctypes.c_void_p(260)) == -5
+    assert adam(n=0) == 0
+    cb = _native.EXCHANGE_FN(lambda *a: 0)
+    op = _native.OperatorC()
+    assert lib.lgc_hop_exchange(ctypes.byref(op), ctypes.byref(op), 100, one, 64, two, 64, None, 0, 1.0, 0.0, 64, 90, 20, 1, cb,
+                                None, None) == -1                                  # exchanged block beyond the table
+    assert lib.lgc_hop_exchange(None, ctypes.byref(op), 100, one, 64, two, 64, None, 0, 1.0, 0.0, 64, 50, 20, 1, cb, None, None) == -1
+
+
 def test_saved_graph_validation_rejects_tampered_tensors():
     from gnn_ecommerce_amd import PropGraph
     rowptr = torch.tensor([0, 2, 3, 5], dtype=torch.int32)
