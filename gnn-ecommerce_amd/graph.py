@@ -190,38 +190,11 @@ class TileClass:
         return self.meta.numel()
 
 
-def _exp_drop_entries(rowptr: Tensor, entries: Tensor, row_begin: int, row_end: int, spec: str) -> Tensor:
-    """DIAGNOSTIC ONLY (LGCN_EXP_DROP, results are numerically meaningless): a copy of ``entries`` in which the entries a
-    per-CU LDS cache would serve are turned into padding (col = -1: no memory access), to bound what such a cache could
-    buy before building it.  spec = "<H>" (the H most gathered columns) or "<H>+cold" (plus every row's coldest column)."""
-    lo, hi = int(rowptr[row_begin]), int(rowptr[row_end])
-    out = entries.clone()
-    hot_n = int(spec.split("+")[0])
-    cols = entries[lo:hi, 0].to(torch.int64)
-    pop = torch.bincount(cols)
-    order = torch.argsort(pop, descending=True, stable=True)
-    rank = torch.empty_like(order)
-    rank[order] = torch.arange(order.numel(), device=order.device)
-    drop = rank[cols] < hot_n
-    if spec.endswith("+cold"):
-        rp = rowptr[row_begin:row_end + 1].to(torch.int64)
-        rows = torch.repeat_interleave(torch.arange(row_end - row_begin, device=rowptr.device), rp[1:] - rp[:-1])
-        key = pop[cols] * (int(cols.max()) + 1) + cols
-        rowmin = torch.full((row_end - row_begin,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=rowptr.device)
-        rowmin.scatter_reduce_(0, rows, key, "amin")
-        drop |= key == rowmin[rows]
-    out[lo:hi, 0] = torch.where(drop, torch.full_like(entries[lo:hi, 0], -1), entries[lo:hi, 0])
-    return out
-
-
 def build_tile_classes(rowptr: Tensor, entries: Tensor, row_begin: int, row_end: int, max_len: int,
                        mode: Optional[str] = None) -> List[TileClass]:
     lib = _native.load()
     classes = []
-    plan_entries = entries
-    if os.environ.get("LGCN_EXP_DROP"):
-        entries = _exp_drop_entries(rowptr, entries, row_begin, row_end, os.environ["LGCN_EXP_DROP"])
-    for width, order, meta in plan_tile_classes(rowptr, plan_entries[:, 0], row_begin, row_end, max_len, mode or TILE_ORDER):
+    for width, order, meta in plan_tile_classes(rowptr, entries[:, 0], row_begin, row_end, max_len, mode or TILE_ORDER):
         slab = torch.empty((order.numel() * width, 2), dtype=torch.int32, device=rowptr.device)
         with torch.cuda.device(rowptr.device):
             code = lib.lgc_build_tiles(_native.ptr(rowptr), _native.ptr(entries), _native.ptr(order), order.numel(), width,
