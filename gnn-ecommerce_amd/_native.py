@@ -71,6 +71,8 @@ SIGNATURES = {
     "lgc_spmm": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32,
                          c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float, c_float,
                          c_int32, c_void_p]),
+    "lgc_spmm_rows": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                              c_void_p, c_int64, c_float, c_float, c_int32, c_void_p]),
     "lgc_build_tiles": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "lgc_spmm_tiles": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int64, c_void_p, c_int64,
                                c_void_p, c_int64, c_void_p, c_int64, c_float, c_float, c_int32, c_void_p]),

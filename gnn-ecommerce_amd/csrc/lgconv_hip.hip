@@ -405,6 +405,64 @@ __device__ __forceinline__ void chunks_body(const SpmmArgs &p, const lgc_chunk *
     }
 }
 
+// A handful of rows given by id (lgc_spmm_rows): one wavefront per listed row.  A training step scores 2B label pairs, so
+// of the last user step's 1.6 M output rows only the <= 2B rows of the batch's users are ever read (src/lightgcn.py:123-125).
+// Rows of up to 32 entries are summed by lane group 0 in entry order -- the same association, hence the same bits, as the
+// tiled kernels and the row-pointer kernel; longer rows are strided over the lane groups and reduced in group order.
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_spmm_rows(SpmmArgs p, const int64_t *__restrict__ row_ids, int64_t n_ids) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t m = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x / kWave);
+    if (m >= n_ids) return;  // wave-uniform
+    const int64_t row = row_ids[m];
+    if (row < p.row_begin || row >= p.row_end) return;   // not a row of this operator half: skipped
+    const int groups = kWave / p.lpr;
+    const int g = lane / p.lpr;
+    const int l = lane - g * p.lpr;
+    const int c0 = lane_column<VEC>(l, p.dim);
+    const bool active = g < groups;
+    const int32_t s = p.rowptr[row], e = p.rowptr[row + 1];
+    const bool short_row = e - s <= 32;                   // wave-uniform
+    const int stride = short_row ? 1 : groups;
+    Acc<VEC> acc;
+    acc.zero();
+    if (active && (!short_row || g == 0)) {
+        const float *xb = p.x + c0;
+        const lgc_entry *__restrict__ ent = p.entries;
+        int32_t k = s + (short_row ? 0 : g);
+        for (; k + 3 * stride < e; k += 4 * stride) {
+            const lgc_entry e0 = ent[k], e1 = ent[k + stride], e2 = ent[k + 2 * stride], e3 = ent[k + 3 * stride];
+            Acc<VEC> x0 = load_row<VEC>(xb + (int64_t)e0.col * p.x_stride);
+            Acc<VEC> x1 = load_row<VEC>(xb + (int64_t)e1.col * p.x_stride);
+            Acc<VEC> x2 = load_row<VEC>(xb + (int64_t)e2.col * p.x_stride);
+            Acc<VEC> x3 = load_row<VEC>(xb + (int64_t)e3.col * p.x_stride);
+            mul_add<VEC>(acc, e0.val, x0);
+            mul_add<VEC>(acc, e1.val, x1);
+            mul_add<VEC>(acc, e2.val, x2);
+            mul_add<VEC>(acc, e3.val, x3);
+        }
+        for (; k < e; k += stride) {
+            const lgc_entry e0 = ent[k];
+            Acc<VEC> x0 = load_row<VEC>(xb + (int64_t)e0.col * p.x_stride);
+            mul_add<VEC>(acc, e0.val, x0);
+        }
+    }
+    if (!short_row) {     // every lane executes the shuffles; only group 0 keeps the result
+        for (int j = 1; j < groups; ++j) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float other = __shfl_down(acc.v[i], j * p.lpr);
+                if (g == 0) acc.v[i] = __fadd_rn(acc.v[i], other);
+            }
+        }
+    }
+    if (!active || g != 0) return;
+    Acc<VEC> rv;
+    rv.zero();
+    if (p.r != nullptr) rv = load_row<VEC>(p.r + row * p.r_stride + c0);
+    finish_row<VEC, SpmmArgs>(p, row, c0, acc, rv);
+}
+
 // One launch per operator and hop: the first `chunk_blocks` workgroups take the chunk work list (long rows
 // are dispatched first, they run longest), the rest the short rows.  Launching the two parts separately
 // left each one's ramp-up and tail exposed -- 7 back-to-back launches per hop of 4-45 us each on a rank of
@@ -1248,29 +1306,6 @@ __global__ void k_lincomb(float *__restrict__ y, int64_t y_stride, LincombArgs a
         for (int t = 1; t < a.n_terms; ++t) v = __fadd_rn(v, __fmul_rn(a.coef[t], a.src[t][row * a.stride[t] + c]));
         y[row * y_stride + c] = v;
     }
-}
-
-// The same, a float4 per thread: dim and every stride a multiple of 4, every base 16-byte aligned (the item blocks of the
-// layer sums at D = 64 / 80 / 128).  One index division per thread instead of one 64-bit division per element.
-__global__ __launch_bounds__(kBlock) void k_lincomb4(float *__restrict__ y, int64_t y_stride, LincombArgs a, uint32_t total4,
-                                                    uint32_t dq) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total4) return;
-    const uint32_t row = i / dq, c = (i - row * dq) * 4u;
-    f4 t[LGC_MAX_TERMS];
-#pragma unroll
-    for (int k = 0; k < LGC_MAX_TERMS; ++k)
-        if (k < a.n_terms) t[k] = *reinterpret_cast<const f4 *>(a.src[k] + (int64_t)row * a.stride[k] + c);
-    float v[4] = {__fmul_rn(a.coef[0], t[0].x), __fmul_rn(a.coef[0], t[0].y), __fmul_rn(a.coef[0], t[0].z), __fmul_rn(a.coef[0], t[0].w)};
-#pragma unroll
-    for (int k = 1; k < LGC_MAX_TERMS; ++k)
-        if (k < a.n_terms) {
-            v[0] = __fadd_rn(v[0], __fmul_rn(a.coef[k], t[k].x));
-            v[1] = __fadd_rn(v[1], __fmul_rn(a.coef[k], t[k].y));
-            v[2] = __fadd_rn(v[2], __fmul_rn(a.coef[k], t[k].z));
-            v[3] = __fadd_rn(v[3], __fmul_rn(a.coef[k], t[k].w));
-        }
-    *reinterpret_cast<f4 *>(y + (int64_t)row * y_stride + c) = f4{v[0], v[1], v[2], v[3]};
 }
 
 // ----------------------------------------------------------------------------------------
@@ -2143,6 +2178,25 @@ int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin,
     });
 }
 
+int lgc_spmm_rows(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin, int32_t row_end, const int64_t *row_ids,
+                  int64_t n_ids, int64_t table_rows, const float *x, int64_t x_stride, float *y, int64_t y_stride, const float *r,
+                  int64_t r_stride, float a, float b, int32_t dim, void *stream_) {
+    DimCfg cfg;
+    if (!dim_cfg(dim, &cfg)) return LGC_E_DIM;
+    if (!rowptr || !x || !y || row_begin < 0 || row_end < row_begin || table_rows < row_end || n_ids < 0 || x == y) return LGC_E_INVAL;
+    if (x_stride < dim || y_stride < dim || (r && r_stride < dim)) return LGC_E_INVAL;
+    if (!aligned_to(x, 4) || !aligned_to(y, 4) || (r && !aligned_to(r, 4))) return LGC_E_ALIGN;
+    if (n_ids == 0) return 0;
+    if (!row_ids || !entries) return LGC_E_INVAL;
+    SpmmArgs p{rowptr, entries, x, y, r, x_stride, y_stride, r_stride, a, b, dim, cfg.lpr, row_begin, row_end, 0, 0};
+    return dispatch_dim(cfg, [&](auto vec) -> int {
+        constexpr int V = decltype(vec)::value;
+        hipLaunchKernelGGL((k_spmm_rows<V>), dim3(ceil_div(n_ids, kBlock / kWave)), dim3(kBlock), 0, as_stream(stream_), p, row_ids,
+                           n_ids);
+        return (int)hipGetLastError();
+    });
+}
+
 int lgc_build_tiles(const int32_t *rowptr, const lgc_entry *entries, const int32_t *order, int64_t n_slots, int32_t width,
                     lgc_entry *slab, void *stream_) {
     if (!rowptr || !order || !slab || n_slots < 0 || (width != 8 && width != 16 && width != 32)) return LGC_E_INVAL;
@@ -2441,14 +2495,6 @@ int lgc_lincomb(float *y, int64_t y_stride, const float *const *src, const int64
         a.coef[t] = coef[t];
     }
     if (n_rows == 0) return 0;
-    bool vec = dim % 4 == 0 && y_stride % 4 == 0 && aligned_to(y, 16) && n_rows * (dim / 4) < (int64_t(1) << 31);
-    for (int t = 0; t < n_terms; ++t) vec = vec && src_stride[t] % 4 == 0 && aligned_to(src[t], 16);
-    if (vec) {
-        const uint32_t total4 = (uint32_t)(n_rows * (dim / 4));
-        hipLaunchKernelGGL(k_lincomb4, dim3(ceil_div(total4, kBlock)), dim3(kBlock), 0, as_stream(stream_), y, y_stride, a, total4,
-                           (uint32_t)(dim / 4));
-        return (int)hipGetLastError();
-    }
     int blocks = (int)std::min<int64_t>(ceil_div(n_rows * dim, kBlock), 256 * 8);
     hipLaunchKernelGGL(k_lincomb, dim3(blocks), dim3(kBlock), 0, as_stream(stream_), y, y_stride, a, n_rows, dim);
     return (int)hipGetLastError();

@@ -419,6 +419,33 @@ class Operator:
         return out
 
 
+def apply_rows(op: "Operator", rows: Tensor, x: Tensor, out: Tensor, a: float = 1.0, r: Optional[Tensor] = None,
+               b: float = 0.0) -> Tensor:
+    """out[row] = a * (A x)[row] + b * r[row] for the rows listed in ``rows`` (int64, on the device; ids outside the
+    operator's plan range are skipped, repeats are harmless); every other row of ``out`` is left untouched.
+    ``lgc_spmm_rows``: one wavefront per listed row."""
+    _check_table(x, "x")
+    _check_table(out, "out")
+    if r is not None:
+        _check_table(r, "r")
+    _native.require_device(rows, "rows")
+    if rows.dtype != torch.int64 or rows.dim() != 1:
+        raise TypeError("rows must be a 1-D int64 tensor")
+    dim = x.size(1)
+    if out.size(1) != dim or (r is not None and r.size(1) != dim):
+        raise ValueError("x, out and r must have the same width")
+    rows = rows.contiguous()
+    lib = _native.load()
+    p = op.plan
+    with torch.cuda.device(x.device):
+        code = lib.lgc_spmm_rows(_native.ptr(op.rowptr), _native.ptr(op.entries), p.row_begin, p.row_end, _native.ptr(rows),
+                                 rows.numel(), min(x.size(0), out.size(0)), _native.ptr(x), x.stride(0), _native.ptr(out),
+                                 out.stride(0), _native.ptr(r), 0 if r is None else r.stride(0), float(a), float(b), dim,
+                                 _native.stream_of(x.device))
+    _native.check(code, "lgc_spmm_rows")
+    return out
+
+
 def sweep_choice(lib, dim: int, table_rows: int, stride: int) -> int:
     """Which band-sweep plan a gathered table of this width gets: 4 / 2 (entries per step), 0 = chunk path."""
     sweep = int(lib.lgc_sweep_ok(dim, table_rows, stride))

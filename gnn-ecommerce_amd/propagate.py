@@ -24,7 +24,7 @@ from torch import Tensor
 from torch.autograd.function import once_differentiable
 
 from . import _native
-from .graph import Operator, PropGraph
+from .graph import Operator, PropGraph, apply_rows
 
 
 # bench.py sets this to a list to receive one (start, end) pair of events per hop, recorded on the
@@ -92,7 +92,8 @@ class _HopSpan:
             self.log.append((self.start, self.end))
 
 
-def bipartite_sum(user_op: Operator, item_op: Operator, split: int, x0: Tensor, alphas: Sequence[float]) -> Tensor:
+def bipartite_sum(user_op: Operator, item_op: Operator, split: int, x0: Tensor, alphas: Sequence[float],
+                  final_rows: Optional[Tensor] = None) -> Tensor:
     """sum_l alpha_l A^l x0 for A = [[0, R], [R^T, 0]] (users first), K = len(alphas) - 1 layers.
 
     With x_l = A^l x0:  x_l[items] = R^T x_{l-1}[users]  (item step, gathers user rows) and
@@ -102,6 +103,11 @@ def bipartite_sum(user_op: Operator, item_op: Operator, split: int, x0: Tensor, 
     so the K-th user table is never materialised, only ONE user step (the last) reads an epilogue row,
     and the weighted sums over layers are taken on the small item tables only (``lgc_lincomb``, in the
     reference's own order: out = out + x * alpha).  Same K item steps + K user steps as K plain hops.
+
+    ``final_rows`` (int64 node ids on the device): the caller will only ever read these rows of the result plus the item
+    block -- a training step scores 2B label pairs (src/lightgcn.py:123-125).  The LAST user step, whose 1.6 M output rows
+    nothing else consumes, is then computed for the listed user rows only (``lgc_spmm_rows``: a few thousand gathers, the
+    same bits for rows of up to 32 entries); every other user row of the result is left uninitialised.
     """
     k = len(alphas) - 1
     if k == 0:
@@ -122,15 +128,22 @@ def bipartite_sum(user_op: Operator, item_op: Operator, split: int, x0: Tensor, 
                 mix = scratch_table(x0)                                         # item rows: sum_l alpha_l x_{l-1}
                 _native.lincomb(mix[split:], [(alphas[l], tables[l - 1][split:]) for l in range(1, k + 1)])
                 _native.lincomb(out[split:], [(alphas[l], tables[l][split:]) for l in range(0, k + 1)])
-                user_op.apply(mix, out, a=1.0, r=x0, b=alphas[0])                # out[users]
+                if final_rows is None:
+                    user_op.apply(mix, out, a=1.0, r=x0, b=alphas[0])            # out[users]
+                else:
+                    apply_rows(user_op, final_rows, mix, out, a=1.0, r=x0, b=alphas[0])
     return out
 
 
-def _layer_sum(graph: PropGraph, x: Tensor, alphas: tuple, transpose: bool) -> Tensor:
+def _layer_sum(graph: PropGraph, x: Tensor, alphas: tuple, transpose: bool, final_rows: Optional[Tensor] = None) -> Tensor:
     if USE_BIPARTITE and graph.split is not None and len(alphas) - 1 <= _native.MAX_TERMS - 1:
         user_op, item_op = graph.halves(transpose)
-        return bipartite_sum(user_op, item_op, graph.split, x, alphas)
+        return bipartite_sum(user_op, item_op, graph.split, x, alphas, final_rows if SCORED_ROWS_ONLY else None)
     return horner_hops(graph.transpose_op if transpose else graph.forward_op, x, alphas)
+
+
+# the forward of a scoring step computes the last user step only for the rows its label pairs name (bipartite_sum)
+SCORED_ROWS_ONLY = os.environ.get("LGCN_SCORED_ROWS_ONLY", "1") == "1"
 
 
 class _PropagateSum(torch.autograd.Function):
@@ -398,8 +411,12 @@ class _ScoresFromTable(torch.autograd.Function):
     @staticmethod
     def forward(ctx, w: Tensor, graph: PropGraph, alphas: tuple, idx0: Tensor, idx1: Tensor, hook: Optional[RegHook]):
         lib = _native.load()
-        emb = _layer_sum(graph, w.detach(), alphas, transpose=False)
         idx0, idx1 = idx0.contiguous(), idx1.contiguous()
+        n_nodes = w.size(0)
+        # only the rows the pairs name are read below (clamped like the gathers that follow, so that every row that is
+        # gathered has been computed): the last user step is restricted to them
+        need = torch.cat([idx0, idx1]).clamp(0, n_nodes - 1)
+        emb = _layer_sum(graph, w.detach(), alphas, transpose=False, final_rows=need)
         scores = torch.empty(idx0.numel(), dtype=torch.float32, device=emb.device)
         with torch.cuda.device(emb.device):
             code = lib.lgc_pair_dot(_native.ptr(emb), emb.stride(0), emb.size(1), emb.size(0), _native.ptr(idx0),

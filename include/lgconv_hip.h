@@ -159,6 +159,16 @@ int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries,
              const float *r, int64_t r_stride,
              float a, float b, int32_t dim, void *stream);
 
+/* The hop of lgc_spmm for a short LIST of rows:  y[row] = a * sum_k val_k * x[col_k] + b * r[row]  for row in row_ids
+ * (int64 [n_ids], device; ids outside [row_begin, row_end) are skipped, repeats are harmless), every other row of y left
+ * untouched.  One wavefront per listed row; rows of up to 32 entries are summed in entry order (the bits of lgc_spmm /
+ * lgc_spmm_tiles), longer ones strided over the lane groups.  What it is for: `LightGCN.forward` in a training step scores
+ * 2B label pairs (src/lightgcn.py:123-125, src/train_lightgcn.py:138), so of the last user step's output only the rows
+ * of the batch's users are ever read -- a few thousand gathers instead of the whole 1.6 M-row step. */
+int lgc_spmm_rows(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin, int32_t row_end, const int64_t *row_ids,
+                  int64_t n_ids, int64_t table_rows, const float *x, int64_t x_stride, float *y, int64_t y_stride, const float *r,
+                  int64_t r_stride, float a, float b, int32_t dim, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Band sweep: long rows over a gathered table far larger than the caches (the item step of a user|item graph).
  *

@@ -346,6 +346,10 @@ def test_argument_errors_of_the_round3_entry_points():
                                           kw.get("bc2", 0.03), None)
     assert adam(w=None) == -1 and adam(n=-1) == -1 and adam(bc2=0.0) == -1 and adam(w=ctypes.c_void_p(260)) == -5
     assert adam(n=0) == 0
+    rows = lambda **kw: lib.lgc_spmm_rows(one, one, 0, kw.get("re", 4), one, kw.get("n", 3), kw.get("tr", 8), one, 64,
+                                          kw.get("y", two), kw.get("ys", 64), None, 0, 1.0, 0.0, kw.get("dim", 64), None)
+    assert rows(dim=300) == -2 and rows(y=one) == -1 and rows(ys=32) == -1 and rows(n=-1) == -1 and rows(re=9) == -1
+    assert rows(n=0) == 0
     cb = _native.EXCHANGE_FN(lambda *a: 0)
     op = _native.OperatorC()
     assert lib.lgc_hop_exchange(ctypes.byref(op), ctypes.byref(op), 100, one, 64, two, 64, None, 0, 1.0, 0.0, 64, 90, 20, 1, cb,
