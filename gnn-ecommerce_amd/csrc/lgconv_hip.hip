@@ -910,8 +910,6 @@ struct SweepArgs {
     int32_t dim, row_cap, n_waves, wave_begin;
     unsigned long long *trace;     // diagnostics only (LGCN_SWEEP_TRACE): [n_waves, 16] s_memrealtime stamps per slab
     int32_t pstride, pcol;         // partial rows are pstride floats, this launch fills columns pcol .. pcol + dim
-    int32_t *progress;             // k_sweep_regs<5>: [n_waves] column every wavefront has reached (zeroed before the launch)
-    int32_t n_bands, throttle;     //   blocks of a band are n_bands apart; sleep when a partner is > throttle columns behind
 };
 
 // A wavefront's piece -> partial-slot table, read ONCE at its start (lane i keeps pieces i, 64 + i, ...) so that the
@@ -1021,68 +1019,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 8))) 
             const f4 a = *reinterpret_cast<const f4 *>(mine + pc * 64);
             __builtin_nontemporal_store(a, reinterpret_cast<f4u *>(p.partials + (int64_t)slot * p.pstride + p.pcol + c0));
         }
-    }
-}
-
-// ----------------------------------------------------------------------------------------
-// The band sweep with the accumulators in REGISTERS (k_sweep_regs, plans with groups = 1)
-// ----------------------------------------------------------------------------------------
-// k_sweep's 158 KiB of LDS accumulators hold a third of a band's pieces, so a band takes three rounds and every table row
-// crosses the fabric once per round that uses it (2.3x by plan, 2.97x measured).  A CU's register file is 512 KiB.  Here
-// a wavefront keeps up to 231 pieces in v24..v254, one register per piece (lane = column; v255 takes the padding), eight
-// wavefronts per CU at 256 registers each: 32 CUs x 8 x 231 = 59 k pieces per band, so a band of the 54.6 k-item graph
-// is ONE round.  The registers are addressed with the VGPR index mode (s_set_gpr_idx_on: a wave-uniform offset added
-// to a VALU operand's register number), which the compiler cannot be asked for across 232 registers: the body is one
-// asm block over fixed registers.
-//   * one entry per step: {col : 24 | piece : 8, val}, 32 entries per 256-byte slab, one dword per lane; lane 2k holds
-//     the packed word of entry k and lane 2k + 1 its weight, fetched with v_readlane into s36.. / s52.. when the gather of
-//     the entry is issued and kept there until it is consumed 16 entries later;
-//   * a gather is one buffer_load_dword per table row (64 lanes x 4 B, the row's byte offset in the scalar offset),
-//     16 in flight per wavefront in v8..v23; vmcnt retires in order, the counts below include the slab load issued in the
-//     middle of every slab (into the register whose entries have all been issued);
-//   * consume: row *= val, then v_add_f32 v[24 + piece] += row under the index mode (a product and a sum, not an fma: the
-//     library is built with -ffp-contract=off so that its sums are the reference's);
-//   * at the end every piece goes to its partial slot, exactly as in k_sweep; k_sweep_combine adds the slots.
-// Tables wider than 64 columns run the same plan once per 64 columns (x, partials and the lane mask shifted).
-typedef int v4i_t __attribute__((ext_vector_type(4)));
-
-#include "sweep_regs.inc"   // tools/gen_sweep_regs.py: LGC_SR_ASM_<variant>, kRegsRowCap_<variant>
-
-template <int VARIANT>   // 0: A16, 1: A32, 4: A8, 5: T16 (two wavefronts per SIMD), 2: B16 (three), 3: C8 (four)
-__global__ __launch_bounds__(kBlock) void k_sweep_regs(SweepArgs p) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wib = threadIdx.x / kWave;
-    const int w = __builtin_amdgcn_readfirstlane((int)(p.wave_begin + blockIdx.x * (kBlock / kWave) + wib));
-    if (w >= p.n_waves) return;
-    const int npieces = __builtin_amdgcn_readfirstlane(p.wave_npieces[w]);
-    const int slab0 = __builtin_amdgcn_readfirstlane(p.wave_slab_ptr[w]);
-    const int nslabs = __builtin_amdgcn_readfirstlane(p.wave_slab_ptr[w + 1]) - slab0;
-    if (npieces <= 0 || nslabs <= 0) return;   // wave-uniform
-    auto rsrc = [](const void *base, uint32_t bytes) {
-        const uint64_t a = (uint64_t)base;
-        return v4i_t{(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
-    };
-    const v4i_t xrs = rsrc(p.x, p.x_bytes);
-    const v4i_t srs = rsrc(reinterpret_cast<const uint32_t *>(p.slabs) + (int64_t)slab0 * 64, (uint32_t)nslabs * 256u);
-    const v4i_t prs = rsrc(p.partials + p.pcol, 0xFFFFFFFFu);
-    const int32_t *slots = p.piece_slot + (int64_t)w * p.row_cap;
-    const unsigned long long mask = p.dim >= 64 ? ~0ull : ((1ull << p.dim) - 1ull);
-    const int l4 = lane * 4;
-    const unsigned xs = (unsigned)p.x_stride * 4u, psb = (unsigned)p.pstride * 4u;
-    const int nsm1 = nslabs - 1, npm1 = npieces - 1;
-    if constexpr (VARIANT == 0) { LGC_SR_ASM_A16 }
-    else if constexpr (VARIANT == 1) { LGC_SR_ASM_A32 }
-    else if constexpr (VARIANT == 2) { LGC_SR_ASM_B16 }
-    else if constexpr (VARIANT == 3) { LGC_SR_ASM_C8 }
-    else if constexpr (VARIANT == 4) { LGC_SR_ASM_A8 }
-    else {
-        // T16: the wavefronts of a band keep together by looking at each other (tools/gen_sweep_regs.py, sync)
-        const int blk = w >> 2, nblk = p.n_waves >> 2, bpb = nblk / p.n_bands;          // blocks per band: a power of two
-        const v4i_t grs = rsrc(p.progress, (uint32_t)p.n_waves * 4u);
-        const unsigned myoff = (unsigned)w * 4u, pb0 = (unsigned)(blk / p.n_bands) + 1u, bmask = (unsigned)bpb - 1u;
-        const unsigned nb16 = (unsigned)p.n_bands * 16u, boff = (unsigned)(blk % p.n_bands) * 16u + (unsigned)(w & 3) * 4u;
-        const int thr = p.throttle;
-        LGC_SR_ASM_T16
     }
 }
 
@@ -1853,8 +1789,8 @@ void parallel_for(int64_t n, F &&f) {
 int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin, int32_t row_end,
                      int32_t col_lo, int32_t col_hi, const lgc_sweep_cfg &cfg) {
     const int NB = cfg.n_bands, WPBR = cfg.waves_per_band_round, CAP = cfg.row_cap;
-    const int GROUPS = cfg.groups == 1 ? 1 : cfg.groups == 2 ? 2 : 4;   // entries per step = rows gathered per instruction
-    const int SLAB = 64 * GROUPS;                        // dwords per 32-step slab: 1 KiB (4 groups), 512 B (2), 256 B (1)
+    const int GROUPS = cfg.groups == 2 ? 2 : 4;          // entries per step = rows a wavefront gathers per instruction
+    const int SLAB = 64 * GROUPS;                        // dwords per 32-step slab: 1 KiB (4 groups) or 512 B (2)
     const int64_t e0 = rowptr[row_begin], e1 = rowptr[row_end];
     const int64_t ne = e1 - e0;
     const int32_t n_rows = row_end - row_begin;
@@ -1982,10 +1918,6 @@ int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry 
             // odd rounds walk their band back down: what the previous round touched last is touched first, while it
             // is still in the Infinity Cache (and, for a few microseconds, in L2)
             if (serpentine && (((w / 4) / NB) / (WPBR / 4)) % 2 == 1) std::reverse(items.begin(), items.end());
-            // one entry per step (k_sweep_regs): the padding names the wave's last real column with weight 0 (a gather
-            // that hits), not an out-of-range id -- the column travels in the scalar offset there
-            const uint32_t pad_entry = (GROUPS == 1 && !items.empty())
-                                           ? (((uint32_t)items.back().col & 0xFFFFFFu) | ((uint32_t)CAP << 24)) : PAD_X;
             done.assign(items.size(), 0);
             size_t head = 0;
             int64_t step = 0, pad = 0;
@@ -1995,7 +1927,7 @@ int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry 
                 if (step % 32 == 0) {
                     const size_t base = out.size();
                     out.resize(base + SLAB);
-                    for (int i = 0; i < SLAB / 2; ++i) { out[base + 2 * i] = pad_entry; out[base + 2 * i + 1] = 0u; }
+                    for (int i = 0; i < SLAB / 2; ++i) { out[base + 2 * i] = PAD_X; out[base + 2 * i + 1] = 0u; }
                 }
                 int used[4], n_used = 0, seen = 0;
                 for (size_t i = head; n_used < GROUPS && i < items.size() && seen < cfg.lookahead; ++i) {
@@ -2057,8 +1989,6 @@ int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry 
 struct Knobs {
     bool no_fast_tiles, no_fused_apply;
     int64_t sweep_launch_waves;
-    int64_t sweep_throttle;   // experiment: k_sweep_regs<5>, columns a wavefront may be ahead of its partner (0 = plain A16)
-    int sweep_bands;
 };
 const Knobs &knobs() {
     static const Knobs k = [] {
@@ -2067,10 +1997,6 @@ const Knobs &knobs() {
         v.no_fused_apply = getenv("LGCN_NO_FUSED_APPLY") != nullptr;
         const char *r = getenv("LGCN_SWEEP_LAUNCH_WAVES");
         v.sweep_launch_waves = r ? atoll(r) : 0;
-        const char *t = getenv("LGCN_SWEEP_THROTTLE");
-        v.sweep_throttle = t ? atoll(t) : 0;
-        const char *nb = getenv("LGCN_SWEEP_BANDS");
-        v.sweep_bands = nb ? atoi(nb) : 8;
         return v;
     }();
     return k;
@@ -2311,7 +2237,7 @@ lgc_sweep_plan *lgc_sweep_plan_create(const int32_t *rowptr_host, const lgc_entr
     if (rowptr_host && (entries_host || rowptr_host[row_end] == rowptr_host[row_begin]) && cfg && row_begin >= 0 &&
         row_end >= row_begin && col_lo >= 0 && col_hi > col_lo && col_hi <= 0xFFFFFF && cfg->n_bands >= 1 &&
         cfg->n_bands <= 64 && cfg->waves_per_band_round >= 4 && cfg->waves_per_band_round % 4 == 0 && cfg->row_cap >= 1 &&
-        cfg->row_cap <= 254 && cfg->piece_cap >= 1 && cfg->lookahead >= 4 && (cfg->groups == 0 || cfg->groups == 1 || cfg->groups == 2 || cfg->groups == 4) &&
+        cfg->row_cap <= 254 && cfg->piece_cap >= 1 && cfg->lookahead >= 4 && (cfg->groups == 0 || cfg->groups == 2 || cfg->groups == 4) &&
         cfg->round_order >= 0 && cfg->round_order <= 2) {
         pl = new (std::nothrow) lgc_sweep_plan();
         if (pl) {
@@ -2375,54 +2301,16 @@ int lgc_spmm_sweep(const uint32_t *slabs, const int32_t *wave_slab_ptr, const in
         row_cap > 254 || x == y)
         return LGC_E_INVAL;
     if (groups == 0) groups = 4;
-    if (groups == 1) {                         // register accumulators: any width up to 128, 64 columns per pass
-        if (dim < 1 || dim > 128 || !sweep_table_ok(dim, table_rows, x_stride)) return LGC_E_DIM;
-        if (row_cap > kRegsRowCap_A8) return LGC_E_INVAL;
-    } else if (lgc_sweep_ok(dim, table_rows, x_stride) != groups) {
-        return LGC_E_DIM;                      // the plan's step width must fit the table
-    }
+    if (lgc_sweep_ok(dim, table_rows, x_stride) != groups) return LGC_E_DIM;    // the plan's step width must fit the table
     if (y_stride < dim || (r && r_stride < dim)) return LGC_E_INVAL;
     if (!aligned_to(x, 4) || !aligned_to(y, 4) || (r && !aligned_to(r, 4)) || !aligned_to(slabs, 16) || !aligned_to(partials, 16))
         return LGC_E_ALIGN;
     hipStream_t stream = as_stream(stream_);
-    const size_t lds = groups == 1 ? 0 : (size_t)(kBlock / kWave) * (size_t)(row_cap + 1) * (groups == 2 ? kWideRow : 64) * sizeof(float);
+    const size_t lds = (size_t)(kBlock / kWave) * (size_t)(row_cap + 1) * (groups == 2 ? kWideRow : 64) * sizeof(float);
     if (lds > 160 * 1024) return LGC_E_INVAL;
-    if (n_waves > 0 && groups == 1) {
-        const unsigned blocks = (unsigned)(n_waves / 4);
-        for (int c0 = 0; c0 < dim; c0 += 64) {
-            const int d = std::min(64, dim - c0);
-            SweepArgs q{reinterpret_cast<const u4 *>(slabs), wave_slab_ptr, wave_npieces, piece_slot, x + c0, partials, x_stride,
-                        (uint32_t)(((table_rows - 1) * x_stride + d) * 4), d, row_cap, (int32_t)n_waves, 0, nullptr, dim, c0, nullptr, 0, 0};
-            // the variant follows from the plan's accumulators per wavefront (more wavefronts per SIMD, fewer registers each)
-            if (row_cap <= kRegsRowCap_C8) hipLaunchKernelGGL(k_sweep_regs<3>, dim3(blocks), dim3(kBlock), 0, stream, q);
-            else if (row_cap <= kRegsRowCap_B16) hipLaunchKernelGGL(k_sweep_regs<2>, dim3(blocks), dim3(kBlock), 0, stream, q);
-            else if (row_cap <= kRegsRowCap_A32) hipLaunchKernelGGL(k_sweep_regs<1>, dim3(blocks), dim3(kBlock), 0, stream, q);
-            else if (row_cap <= kRegsRowCap_T16 && knobs().sweep_throttle > 0) {
-                // the throttled variant: one band = blocks b, b + n_bands, ...; their number must be a power of two
-                static int32_t *progress[64] = {};
-                static int64_t progress_len[64] = {};
-                int dev = 0;
-                const int nb = knobs().sweep_bands;
-                const int64_t bpb = nb > 0 ? (n_waves / 4) / nb : 0;
-                if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LGC_E_INVAL;
-                if (bpb < 1 || (bpb & (bpb - 1)) != 0 || bpb * nb * 4 != n_waves) return LGC_E_INVAL;
-                if (progress_len[dev] < n_waves) {
-                    if (progress[dev]) (void)hipFree(progress[dev]);
-                    if (hipMalloc(&progress[dev], (size_t)n_waves * 4) != hipSuccess) return (int)hipErrorOutOfMemory;
-                    progress_len[dev] = n_waves;
-                }
-                (void)hipMemsetAsync(progress[dev], 0, (size_t)n_waves * 4, stream);
-                q.progress = progress[dev];
-                q.n_bands = nb;
-                q.throttle = (int32_t)knobs().sweep_throttle;
-                hipLaunchKernelGGL(k_sweep_regs<5>, dim3(blocks), dim3(kBlock), 0, stream, q);
-            }
-            else if (row_cap <= kRegsRowCap_A16) hipLaunchKernelGGL(k_sweep_regs<0>, dim3(blocks), dim3(kBlock), 0, stream, q);
-            else hipLaunchKernelGGL(k_sweep_regs<4>, dim3(blocks), dim3(kBlock), 0, stream, q);
-        }
-    } else if (n_waves > 0) {
+    if (n_waves > 0) {
         SweepArgs p{reinterpret_cast<const u4 *>(slabs), wave_slab_ptr, wave_npieces, piece_slot, x, partials, x_stride,
-                    (uint32_t)(((table_rows - 1) * x_stride + dim) * 4), dim, row_cap, (int32_t)n_waves, 0, nullptr, dim, 0, nullptr, 0, 0};
+                    (uint32_t)(((table_rows - 1) * x_stride + dim) * 4), dim, row_cap, (int32_t)n_waves, 0, nullptr, dim, 0};
         const bool two_pass = groups == 4 && dim > 64;   // columns [0, 64) and [64, dim) as two sweeps of the same plan
         if (two_pass) {
             p.dim = 64;
@@ -2467,8 +2355,7 @@ int lgc_spmm_sweep(const uint32_t *slabs, const int32_t *wave_slab_ptr, const in
 int lgc_apply(const lgc_operator *op, int64_t table_rows, const float *x, int64_t x_stride, float *y, int64_t y_stride,
               const float *r, int64_t r_stride, float a, float b, int32_t dim, void *stream) {
     if (!op || op->n_tile_classes < 0 || op->n_tile_classes > 3) return LGC_E_INVAL;
-    if (op->sweep && (op->sweep->groups == 1 ? (dim >= 1 && dim <= 128 && sweep_table_ok(dim, table_rows, x_stride))
-                                             : lgc_sweep_ok(dim, table_rows, x_stride) == (op->sweep->groups ? op->sweep->groups : 4))) {
+    if (op->sweep && lgc_sweep_ok(dim, table_rows, x_stride) == (op->sweep->groups ? op->sweep->groups : 4)) {
         const lgc_sweep_arrays *sw = op->sweep;
         return lgc_spmm_sweep(sw->slabs, sw->wave_slab_ptr, sw->wave_npieces, sw->piece_slot, sw->n_waves, sw->row_cap,
                               sw->groups, sw->multi, sw->n_rows, sw->multi_wide, sw->n_wide, sw->partials, table_rows, x, x_stride, y,

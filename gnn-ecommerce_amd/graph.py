@@ -57,18 +57,6 @@ SWEEP_CFG = dict(n_bands=int(os.environ.get("LGCN_SWEEP_BANDS", "8")), waves_per
 SWEEP_WIDE = os.environ.get("LGCN_SWEEP_WIDE", "1") == "1"
 # tables of 68..96 columns: a row takes two DPP rows, LDS rows are 96 floats -> 51 accumulators per wavefront
 SWEEP_CFG_WIDE = dict(SWEEP_CFG, row_cap=int(os.environ.get("LGCN_SWEEP_ROW_CAP_WIDE", "51")), groups=2)
-# accumulators in registers (k_sweep_regs): one entry per step, any width up to 128
-SWEEP_REGS = os.environ.get("LGCN_SWEEP_REGS", "0") == "1"
-# variants (tools/gen_sweep_regs.py): wavefronts per SIMD x gathers in flight -> accumulators per wavefront
-SWEEP_REGS_VARIANTS = {"A8": dict(row_cap=244, waves_per_band_round=256), "A16": dict(row_cap=236, waves_per_band_round=256),
-                       "T16": dict(row_cap=234, waves_per_band_round=256), "A32": dict(row_cap=220, waves_per_band_round=256),
-                       "B16": dict(row_cap=148, waves_per_band_round=384), "C8": dict(row_cap=116, waves_per_band_round=512)}
-SWEEP_CFG_REGS = dict(SWEEP_CFG, groups=1, **SWEEP_REGS_VARIANTS["A16"])
-
-
-def _regs_cfg() -> dict:
-    v = os.environ.get("LGCN_SWEEP_REGS_VARIANT", "")
-    return dict(SWEEP_CFG_REGS, **SWEEP_REGS_VARIANTS[v]) if v else SWEEP_CFG_REGS
 
 
 @dataclass
@@ -331,13 +319,12 @@ class Operator:
         (68..96 columns) per gather instruction; built on first use."""
         if self.sweep_cols is None:
             return None
-        cfg = _regs_cfg() if groups == 1 else SWEEP_CFG_WIDE if groups == 2 else SWEEP_CFG
-        key = groups if groups != 1 else (1, cfg["row_cap"], cfg["waves_per_band_round"])
-        plan = self._sweep.get(key)
+        plan = self._sweep.get(groups)
         if plan is None:
             p = self.plan
-            plan = SweepPlan(self.rowptr, self.entries, p.row_begin, p.row_end, *self.sweep_cols, cfg=cfg)
-            self._sweep[key] = plan
+            plan = SweepPlan(self.rowptr, self.entries, p.row_begin, p.row_end, *self.sweep_cols,
+                             cfg=SWEEP_CFG_WIDE if groups == 2 else SWEEP_CFG)
+            self._sweep[groups] = plan
         return plan
 
     @property
@@ -376,7 +363,7 @@ class Operator:
         """The operator as the C ABI's ``lgc_operator`` (device pointers of tensors this object keeps alive), cached per
         embedding width because the scratch buffers are per width."""
         import ctypes
-        key = (dim, sweep) if sweep != 1 else (dim, sweep, os.environ.get("LGCN_SWEEP_REGS_VARIANT", ""))
+        key = (dim, sweep)
         got = self._c_structs.get(key)
         if got is not None:
             return got[0]
@@ -395,7 +382,7 @@ class Operator:
                                                 tc.width)
             c.n_tile_classes = len(self.tiles)
         if sweep:                                   # 4 or 2 = lgc_sweep_ok's answer for this table
-            sw = self.sweep_plan(int(sweep) if int(sweep) in (1, 2, 4) else 4)
+            sw = self.sweep_plan(int(sweep) if int(sweep) in (2, 4) else 4)
             sc = _native.SweepArraysC(_native.ptr(sw.slabs), _native.ptr(sw.wave_slab_ptr), _native.ptr(sw.wave_npieces),
                                       _native.ptr(sw.piece_slot), _native.ptr(sw.multi) if sw.multi.size(0) else None,
                                       _native.ptr(sw.multi_wide) if sw.multi_wide.size(0) else None,
@@ -462,8 +449,6 @@ def apply_rows(op: "Operator", rows: Tensor, x: Tensor, out: Tensor, a: float = 
 def sweep_choice(lib, dim: int, table_rows: int, stride: int) -> int:
     """Which band-sweep plan a gathered table of this width gets: 4 / 2 (entries per step), 0 = chunk path."""
     sweep = int(lib.lgc_sweep_ok(dim, table_rows, stride))
-    if sweep and os.environ.get("LGCN_SWEEP_REGS", "1" if SWEEP_REGS else "0") == "1":
-        return 1
     return 0 if (sweep == 2 and not SWEEP_WIDE) else sweep
 
 

@@ -787,62 +787,6 @@ def test_band_sweep_matches_the_oracle_and_the_chunked_path(device, dim, monkeyp
     assert rel_fro(y66[nu:].cpu(), oracle.lgconv(x66.cpu(), ei, ew)[nu:]) <= TOL
 
 
-@pytest.mark.parametrize("dim", [64, 61, 90, 68, 80, 96, 128, 100])
-def test_register_sweep_matches_the_oracle_and_the_lds_sweep(device, dim, monkeypatch):
-    """k_sweep_regs (plans with groups = 1: accumulators in registers under the VGPR index mode, one entry per step, 64
-    columns per pass): vs the oracle hop, vs the chunked path, deterministic, epilogue, a strided table, plans with one
-    and with several rounds, wavefronts with a single slab, fewer pieces than a write-out trip."""
-    from gnn_ecommerce_amd import graph as G
-    from gnn_ecommerce_amd.graph import Operator
-    g, ei, ew = small_graph(8, 6000, 150, 90000)
-    n, nu = g.num_nodes, g.n_users
-    pg = PropGraph(ei.to(device), ew.to(device), n)
-    op = pg.forward_op
-    x, r = synth.xavier_table(n, dim, 5), synth.xavier_table(n, dim, 6)
-    want = oracle.lgconv(x, ei, ew)
-    xd, rd = x.to(device), r.to(device)
-    monkeypatch.setattr(G, "USE_SWEEP", "1")
-    monkeypatch.setenv("LGCN_SWEEP_REGS", "1")
-    chunked = Operator.build(n, op.rowptr, op.entries, nu, n, 32, 256)
-    yc = torch.empty((n, dim), device=device)
-    chunked.apply(xd, yc)
-    # row_cap picks the kernel variant: <= 116 four wavefronts per SIMD and 8 gathers in flight, <= 148 three and 16,
-    # <= 220 two and 32, <= 236 two and 16
-    for cfg in (dict(waves_per_band_round=8, row_cap=236), dict(waves_per_band_round=4, row_cap=3, piece_cap=16),
-                dict(waves_per_band_round=256, row_cap=220), dict(n_bands=3, waves_per_band_round=4, row_cap=40),
-                dict(waves_per_band_round=12, row_cap=148), dict(waves_per_band_round=16, row_cap=116),
-                dict(n_bands=2, waves_per_band_round=4, row_cap=200, piece_cap=16)):
-        monkeypatch.setattr(G, "SWEEP_CFG_REGS", dict(G.SWEEP_CFG_REGS, **cfg))
-        sw = Operator.build(n, op.rowptr, op.entries, nu, n, 32, 256, sweep_cols=(0, nu))
-        y = torch.full((n, dim), float("nan"), device=device)
-        sw.apply(xd, y)
-        (plan,) = sw._sweep.values()
-        assert plan.dims["groups"] == 1 and plan.dims["row_cap"] == cfg["row_cap"] and plan.dims["n_entries"] == g.nnz // 2
-        got = y[nu:].cpu()
-        assert rel_fro(got, want[nu:]) <= TOL and worst_row_rel(got, want[nu:]) <= TOL
-        assert rel_fro(got, yc[nu:].cpu()) <= 1e-6
-        assert torch.isnan(y[:nu]).all()
-        y2 = torch.empty_like(y)
-        sw.apply(xd, y2)
-        assert torch.equal(y2[nu:], y[nu:])
-        ye = torch.empty_like(y)
-        sw.apply(xd, ye, a=0.5, r=rd, b=0.25)
-        assert rel_fro(ye[nu:].cpu(), 0.5 * want[nu:] + 0.25 * r[nu:]) <= TOL
-        wide = torch.zeros((n, dim + 8), device=device)
-        wide[:, :dim] = xd
-        ys = torch.empty_like(y)
-        sw.apply(wide[:, :dim], ys)
-        assert torch.equal(ys[nu:], y[nu:])
-    if dim in (61, 64):       # the same sums in the same order as the LDS sweep of the same bands: equal bits
-        monkeypatch.setenv("LGCN_SWEEP_REGS", "0")
-        monkeypatch.setattr(G, "SWEEP_CFG", dict(G.SWEEP_CFG, n_bands=3, waves_per_band_round=4, row_cap=78, round_order=0))
-        lds = Operator.build(n, op.rowptr, op.entries, nu, n, 32, 256, sweep_cols=(0, nu))
-        yl = torch.empty_like(y)
-        lds.apply(xd, yl)
-        assert list(lds._sweep) == [4]
-        assert rel_fro(yl[nu:].cpu(), y[nu:].cpu()) <= 1e-6
-
-
 @pytest.mark.parametrize("rows,cols,k", [(1, 54571, 20), (7, 1000, 5), (3, 300, 256), (5, 64, 64), (2, 5000, 1),
                                          (3, 1024, 7), (2, 1025, 3), (2, 65536, 33), (2, 70001, 20)])
 def test_mask_topk_matches_torch_and_breaks_ties_by_index(device, rows, cols, k):
