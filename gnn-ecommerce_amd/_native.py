@@ -17,7 +17,7 @@ import torch
 LIB_NAME = "liblgconv_hip.so"
 # LGCN_LIB_PATH selects another build of the SAME library (A/B kernel experiments); never a fallback.
 LIB_PATH = os.environ.get("LGCN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", LIB_NAME)
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 # status bits (include/lgconv_hip.h)
 ST_INDEX_OOB = 1
@@ -92,7 +92,8 @@ SIGNATURES = {
     "lgc_segment_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_int64, c_int64, c_int32, c_int32,
                                 c_void_p]),
     "lgc_seed_pull": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p,
-                              c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int32, c_void_p]),
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int32, c_void_p]),
+    "lgc_seed_mark": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p]),
     "lgc_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
                               c_float, c_void_p]),
     "lgc_lincomb": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p]),

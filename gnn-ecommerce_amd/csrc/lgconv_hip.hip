@@ -199,6 +199,7 @@ struct SpmmArgs {
     // seeded pull (lgc_seed_pull): only columns with col_flag != 0 are gathered, from row col_slot[col] of x
     const uint8_t *col_flag;
     const int32_t *col_slot;
+    const uint8_t *row_mark;   // optional: rows with row_mark[row] == 0 have no flagged column and are written as zeros unread
 };
 
 // A lane's slice of a row: VEC consecutive floats starting at column c0.
@@ -312,6 +313,14 @@ __device__ __forceinline__ void rows_body(const SpmmArgs &p, int64_t block) {
 
     const int32_t s = p.rowptr[row], e = p.rowptr[row + 1];
     if (e - s > p.short_max) return;  // belongs to the chunk part
+    if constexpr (FILTER) {
+        if (p.row_mark != nullptr && p.row_mark[row] == 0) {   // no seed among this row's columns (lgc_seed_mark)
+            Acc<VEC> zero;
+            zero.zero();
+            store_out<VEC, SpmmArgs>(p, row, c0, zero);
+            return;
+        }
+    }
 
     const float *xb = p.x + c0;
     const lgc_entry *__restrict__ ent = p.entries;
@@ -356,7 +365,9 @@ __device__ __forceinline__ void chunks_body(const SpmmArgs &p, const lgc_chunk *
 
     Acc<VEC> acc;
     acc.zero();
-    if (active) {
+    bool unmarked = false;   // wave-uniform: the chunk's row has no seed among its columns -> a zero partial / zero row
+    if constexpr (FILTER) unmarked = p.row_mark != nullptr && p.row_mark[ch.row] == 0;
+    if (active && !unmarked) {
         const float *xb = p.x + c0;
         const lgc_entry *__restrict__ ent = p.entries;
         int32_t k = ch.begin + g;
@@ -1287,6 +1298,22 @@ __global__ __launch_bounds__(kBlock) void k_segment_sum(const int64_t *__restric
     float *out = y + d * y_stride + c0;
     for (int i = 0; i < 4; ++i)
         if (c0 + i < dim) out[i] = __fadd_rn(accumulate ? out[i] : 0.0f, __fmul_rn(scale, acc[i]));
+}
+
+// The columns of the listed rows get `value` in `mark` (lgc_seed_mark): the rows the seeded pull has to look at.  Every
+// writer stores the same byte, so the order does not matter.
+__global__ void k_seed_mark(const int32_t *__restrict__ rowptr, const lgc_entry *__restrict__ entries, int32_t row_begin,
+                            int32_t row_end, const int64_t *__restrict__ seed_rows, int64_t n_seed, uint8_t *__restrict__ mark,
+                            int64_t mark_len, uint8_t value) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_seed) return;
+    const int64_t row = seed_rows[t];
+    if (row < row_begin || row >= row_end) return;
+    if (t > 0 && seed_rows[t - 1] == row) return;        // sorted lists: a repeated row is marked once
+    for (int32_t k = rowptr[row]; k < rowptr[row + 1]; ++k) {
+        const int32_t c = entries[k].col;
+        if (c >= 0 && c < mark_len) mark[c] = value;
+    }
 }
 
 struct LincombArgs {
@@ -2450,10 +2477,20 @@ int lgc_segment_sum(const int64_t *key_sorted, const int64_t *dest, const float 
     return (int)hipGetLastError();
 }
 
+int lgc_seed_mark(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin, int32_t row_end, const int64_t *seed_rows,
+                  int64_t n_seed, uint8_t *mark, int64_t mark_len, int32_t value, void *stream_) {
+    if (n_seed < 0 || row_begin < 0 || row_end < row_begin || mark_len < 0 || value < 0 || value > 255) return LGC_E_INVAL;
+    if (n_seed == 0) return 0;
+    if (!rowptr || !entries || !seed_rows || !mark) return LGC_E_INVAL;
+    hipLaunchKernelGGL(k_seed_mark, dim3(ceil_div(n_seed, (int64_t)kBlock)), dim3(kBlock), 0, as_stream(stream_), rowptr, entries,
+                       row_begin, row_end, seed_rows, n_seed, mark, mark_len, (uint8_t)value);
+    return (int)hipGetLastError();
+}
+
 int lgc_seed_pull(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin, int32_t row_end, int32_t short_max,
                   const lgc_chunk *chunks, int32_t n_chunks, const lgc_multi_row *multi, int32_t n_multi, float *partials,
-                  const uint8_t *col_flag, const int32_t *col_slot, const float *seed_vals, int64_t seed_stride,
-                  int64_t table_rows, float *y, int64_t y_stride, int32_t dim, void *stream_) {
+                  const uint8_t *col_flag, const int32_t *col_slot, const uint8_t *row_mark, const float *seed_vals,
+                  int64_t seed_stride, int64_t table_rows, float *y, int64_t y_stride, int32_t dim, void *stream_) {
     DimCfg cfg;
     if (!dim_cfg(dim, &cfg)) return LGC_E_DIM;
     if (!rowptr || !col_flag || !col_slot || !seed_vals || !y || row_begin < 0 || row_end < row_begin || n_chunks < 0 ||
@@ -2463,7 +2500,7 @@ int lgc_seed_pull(const int32_t *rowptr, const lgc_entry *entries, int32_t row_b
     if (!aligned_to(seed_vals, 4) || !aligned_to(y, 4)) return LGC_E_ALIGN;
     hipStream_t stream = as_stream(stream_);
     SpmmArgs p{rowptr, entries, seed_vals, y, nullptr, seed_stride, y_stride, 0, 1.0f, 0.0f, dim, cfg.lpr, row_begin, row_end,
-               short_max, 0, col_flag, col_slot};
+               short_max, 0, col_flag, col_slot, row_mark};
     const int waves_per_block = kBlock / kWave;
     const int rows_per_wave = kWave / cfg.lpr;
     return dispatch_dim(cfg, [&](auto vec) -> int {

@@ -289,18 +289,30 @@ SPARSE_BACKWARD = os.environ.get("LGCN_SPARSE_BACKWARD", "1") == "1"
 SEED_ROWS_FACTOR = int(os.environ.get("LGCN_SEED_ROWS_FACTOR", "32"))
 
 
-def _seed_pull(op: Operator, flag: Tensor, slot: Tensor, seed_vals: Tensor, out: Tensor) -> None:
+def _seed_pull(op: Operator, flag: Tensor, slot: Tensor, seed_vals: Tensor, out: Tensor, mark: Optional[Tensor] = None) -> None:
     """out[rows of op] = sum over the entries whose column carries a flag of val * seed_vals[slot[col]] (lgc_seed_pull):
-    the rows of ``op`` through its row / chunk plan in lgc_spmm's fixed order."""
+    the rows of ``op`` through its row / chunk plan in lgc_spmm's fixed order; rows whose ``mark`` byte is 0 are written
+    as zeros without being read."""
     lib = _native.load()
     p = op.plan
     with torch.cuda.device(out.device):
         code = lib.lgc_seed_pull(_native.ptr(op.rowptr), _native.ptr(op.entries), p.row_begin, p.row_end, p.short_max,
                                  _native.ptr(p.chunks) if p.n_chunks else None, p.n_chunks,
                                  _native.ptr(p.multi) if p.n_multi else None, p.n_multi, _native.ptr(op.partials(out.size(1))),
-                                 _native.ptr(flag), _native.ptr(slot), _native.ptr(seed_vals), seed_vals.stride(0),
-                                 out.size(0), _native.ptr(out), out.stride(0), out.size(1), _native.stream_of(out.device))
+                                 _native.ptr(flag), _native.ptr(slot), _native.ptr(mark), _native.ptr(seed_vals),
+                                 seed_vals.stride(0), out.size(0), _native.ptr(out), out.stride(0), out.size(1),
+                                 _native.stream_of(out.device))
     _native.check(code, "lgc_seed_pull")
+
+
+def _seed_mark(op: Operator, rows_sorted: Tensor, mark: Tensor, value: int) -> None:
+    """mark[col] = value for every column of the rows of ``op`` listed in ``rows_sorted`` (lgc_seed_mark)."""
+    lib = _native.load()
+    p = op.plan
+    with torch.cuda.device(mark.device):
+        code = lib.lgc_seed_mark(_native.ptr(op.rowptr), _native.ptr(op.entries), p.row_begin, p.row_end, _native.ptr(rows_sorted),
+                                 rows_sorted.numel(), _native.ptr(mark), mark.numel(), int(value), _native.stream_of(mark.device))
+    _native.check(code, "lgc_seed_mark")
 
 
 _seed_maps = {}
@@ -316,6 +328,20 @@ def _seed_map_buffers(device: torch.device, n_cols: int):
     return got
 
 
+_seed_marks = {}
+# item rows without a seed user among their columns are written as zeros unread (lgc_seed_mark); "0" reads every row
+SEED_MARKS = os.environ.get("LGCN_SEED_MARKS", "1") == "1"
+
+
+def _seed_mark_buffer(device: torch.device, n_rows: int) -> Tensor:
+    """Per device: one byte per table row, all zero between uses."""
+    got = _seed_marks.get(device)
+    if got is None or got.numel() < n_rows:
+        got = torch.zeros(n_rows, dtype=torch.uint8, device=device)
+        _seed_marks[device] = got
+    return got
+
+
 def seeded_transpose_sum(graph: PropGraph, rows: Tensor, vals: Tensor, alphas: Sequence[float], n: int,
                          extra: Optional[Sequence] = None) -> Tensor:
     """sum_l alpha_l (A^T)^l g for a gradient g given by its non-zero rows (``rows`` int64, repeats add up; ``vals`` [len, D])
@@ -324,7 +350,8 @@ def seeded_transpose_sum(graph: PropGraph, rows: Tensor, vals: Tensor, alphas: S
         the gradient has the same bits on every run, like the reference's CPU path);
       * hop 1, item side: only edges between an item and a seed USER matter -> lgc_seed_pull over the item rows of A^T
         (an entry counts if its user carries a flag; it then reads that user's row of the compact seed table) instead of
-        a dense item step gathering 10 M rows of zeros;
+        a dense item step gathering 10 M rows of zeros, and only over the item rows some seed user's own row names
+        (lgc_seed_mark: ~6 per seed user of 54 k) -- the others are zeros without a look at their entries;
       * hop 1, user side: the dense user step, reading only the 14 MB item block of g (the rest of that table is never
         initialised, let alone zero-filled);
       * the alpha_0 g term of the user rows is added to the seed rows afterwards instead of being read as a dense
@@ -372,10 +399,15 @@ def seeded_transpose_sum(graph: PropGraph, rows: Tensor, vals: Tensor, alphas: S
         with _HopSpan():
             nxt = scratch_table(g_tab)
             if layer == 1:
+                mark = _seed_mark_buffer(dev, n) if SEED_MARKS else None
                 try:
-                    _seed_pull(item_t, flag, slot, gu, nxt)                     # x_1[items] from the seed users
+                    if mark is not None:                                        # the item rows next to a seed user: the only
+                        _seed_mark(user_t, rows_s, mark, 1)                     # rows the pull has to read
+                    _seed_pull(item_t, flag, slot, gu, nxt, mark)               # x_1[items] from the seed users
                 finally:
-                    flag[fidx] = 0                                              # the flags are all zero between steps
+                    flag[fidx] = 0                                              # flags and marks are all zero between steps
+                    if mark is not None:
+                        _seed_mark(user_t, rows_s, mark, 0)
             else:
                 item_t.apply(tables[-1], nxt)
             if layer < k:

@@ -331,7 +331,7 @@ def test_cold_order_puts_rows_sharing_a_rare_column_next_to_each_other():
 
 
 def test_argument_errors_of_the_round3_entry_points():
-    """lgc_segment_sum, lgc_seed_pull, lgc_adam_step, lgc_hop_exchange: bad arguments are refused before any launch."""
+    """lgc_segment_sum, lgc_seed_pull, lgc_seed_mark, lgc_adam_step, lgc_hop_exchange: bad arguments are refused before any launch."""
     lib = _native.load()
     one, two = ctypes.c_void_p(256), ctypes.c_void_p(512)
     seg = lambda **kw: lib.lgc_segment_sum(kw.get("key", one), one, one, kw.get("n", 8), 1.0, kw.get("y", two), kw.get("ys", 64),
@@ -339,9 +339,14 @@ def test_argument_errors_of_the_round3_entry_points():
     assert seg(y=None) == -1 and seg(n=-1) == -1 and seg(dim=0) == -1 and seg(dim=300) == -1 and seg(ys=32) == -1
     assert seg(key=None) == -1 and seg(n=0) == 0                                  # nothing to do is not an error
     pull = lambda **kw: lib.lgc_seed_pull(one, one, 0, 4, 32, None, kw.get("n_chunks", 0), None, 0, None, kw.get("flag", one),
-                                          one, one, kw.get("ss", 64), 8, kw.get("y", two), 64, kw.get("dim", 64), None)
+                                          one, kw.get("mark", None), one, kw.get("ss", 64), 8, kw.get("y", two), 64,
+                                          kw.get("dim", 64), None)
     assert pull(dim=300) == -2 and pull(flag=None) == -1 and pull(ss=32) == -1 and pull(n_chunks=3) == -1
-    assert pull(y=ctypes.c_void_p(514)) == -5
+    assert pull(y=ctypes.c_void_p(514)) == -5 and pull(mark=one, y=ctypes.c_void_p(514)) == -5     # the marks are optional
+    mark = lambda **kw: lib.lgc_seed_mark(kw.get("rp", one), one, 0, kw.get("re", 4), kw.get("rows", one), kw.get("n", 3),
+                                          kw.get("mark", two), kw.get("len", 8), kw.get("value", 1), None)
+    assert mark(rp=None) == -1 and mark(rows=None) == -1 and mark(mark=None) == -1 and mark(n=-1) == -1 and mark(re=-1) == -1
+    assert mark(len=-1) == -1 and mark(value=256) == -1 and mark(value=-1) == -1 and mark(n=0) == 0
     adam = lambda **kw: lib.lgc_adam_step(kw.get("w", one), one, one, one, kw.get("n", 64), 0.1, 0.999, 0.001, 1e-8, 0.005,
                                           kw.get("bc2", 0.03), None)
     assert adam(w=None) == -1 and adam(n=-1) == -1 and adam(bc2=0.0) == -1 and adam(w=ctypes.c_void_p(260)) == -5

@@ -878,6 +878,48 @@ def test_recommendk_frame_is_upstreams_frame(device):
                                  ((users_e[users] @ items_e.t()) * (1 - seen)).numpy())
 
 
+@pytest.mark.parametrize("dim", [64, 90, 7, 1, 128])
+def test_segment_sum_is_a_fixed_order_run_sum(device, dim):
+    """lgc_segment_sum against a loop restatement of its header comment: runs of equal sorted keys, heads whose dest is
+    negative or out of range skipped, scale, accumulate, one long run (thousands of terms), n = 0 and n = 1 -- bit for
+    bit a sequential fp32 sum, and the same bits on every call (no atomics)."""
+    from gnn_ecommerce_amd.propagate import segment_sum
+    gen = torch.Generator().manual_seed(dim)
+    runs = [1, 1, 2, 3, 1, 40, 1, 5000, 7, 1, 1, 64, 33]
+    keys = torch.repeat_interleave(torch.arange(len(runs)) * 3 + 5, torch.tensor(runs))
+    n, y_rows = keys.numel(), 50
+    dest_of_run = torch.tensor([4, 9, -1, 0, 49, 17, 50, 3, 1000, 2, 8, 30, 31])       # -1, 50, 1000: skipped
+    dest = torch.full((n,), -7, dtype=torch.int64)
+    heads = torch.cumsum(torch.tensor([0] + runs[:-1]), 0)
+    dest[heads] = dest_of_run
+    vals = torch.randn(n, dim, generator=gen)
+    base = torch.randn(y_rows, dim, generator=gen)
+    for scale, acc in ((1.0, False), (0.125, True)):
+        want = base.clone()
+        for h, ln, d in zip(heads.tolist(), runs, dest_of_run.tolist()):
+            if 0 <= d < y_rows:                      # the kernel's arithmetic: a sequential fp32 sum, then one scale, one add
+                tot = torch.zeros(dim)
+                for t in range(h, h + ln):
+                    tot = tot + vals[t]
+                want[d] = (want[d] if acc else torch.zeros(dim)) + torch.tensor(scale) * tot
+        out = base.clone().to(device)
+        segment_sum(keys.to(device), dest.to(device), vals.to(device), out, scale=scale, accumulate=acc)
+        touched = torch.tensor([d for d in dest_of_run.tolist() if 0 <= d < y_rows])
+        assert torch.equal(out[touched].cpu(), want[touched])
+        untouched = torch.ones(y_rows, dtype=torch.bool)
+        untouched[touched] = False
+        assert torch.equal(out.cpu()[untouched], base[untouched])
+        out2 = base.clone().to(device)
+        segment_sum(keys.to(device), dest.to(device), vals.to(device), out2, scale=scale, accumulate=acc)
+        assert torch.equal(out2, out)
+    empty = torch.zeros(y_rows, dim, device=device)
+    segment_sum(keys[:0].to(device), dest[:0].to(device), vals[:0].to(device), empty)
+    assert (empty == 0).all()
+    one = torch.zeros(y_rows, dim, device=device)
+    segment_sum(keys[:1].to(device), torch.tensor([7], device=device), vals[:1].to(device), one, scale=2.0)
+    assert torch.equal(one[7].cpu(), 2.0 * vals[0]) and one.abs().sum(dim=1).count_nonzero() <= 1
+
+
 @pytest.mark.parametrize("dim", [64, 90, 7, 128])
 def test_listed_rows_hop_equals_the_full_hop(device, dim):
     """lgc_spmm_rows: the hop for a list of rows (the last user step of a scoring forward) against the full user step --
@@ -908,6 +950,29 @@ def test_listed_rows_hop_equals_the_full_hop(device, dim):
     out2 = torch.full_like(x, float("nan"))
     apply_rows(user_op, rows, x, out2, a=0.5, r=r, b=0.25)
     assert torch.equal(out2[listed], out[listed])                          # deterministic
+
+
+def test_seed_marks_name_exactly_the_neighbours_of_the_seed_rows(device):
+    """lgc_seed_mark: the columns of the listed rows and nothing else; ids outside the operator half and repeats are
+    harmless; value 0 takes the marks back."""
+    from gnn_ecommerce_amd.propagate import _seed_mark
+    g, ei, ew = small_graph(3, 500, 90, 4000)
+    n, nu = g.num_nodes, g.n_users
+    pg = PropGraph(ei.to(device), ew.to(device), n)
+    user_t, item_t = pg.halves(True)
+    seeds = torch.tensor([3, 3, 17, 250, 499, nu + 4, n + 9], device=device)          # sorted; the last two are not user rows
+    mark = torch.zeros(n, dtype=torch.uint8, device=device)
+    _seed_mark(user_t, seeds, mark, 1)
+    want = torch.zeros(n, dtype=torch.uint8)
+    rp, cols = user_t.rowptr.cpu(), user_t.columns().cpu().long()
+    for u in (3, 17, 250, 499):
+        want[cols[rp[u]:rp[u + 1]]] = 1
+    assert torch.equal(mark.cpu(), want) and want[:nu].sum() == 0 and want.sum() > 0
+    _seed_mark(user_t, seeds, mark, 0)
+    assert int(mark.sum()) == 0
+    short = torch.zeros(nu + 5, dtype=torch.uint8, device=device)                     # columns past the buffer are skipped
+    _seed_mark(user_t, seeds, short, 7)
+    assert torch.equal(short.cpu(), want[:nu + 5] * 7)
 
 
 @pytest.mark.parametrize("dim,layers", [(64, 3), (90, 5), (16, 1), (64, 0)])
@@ -958,6 +1023,13 @@ def test_seeded_backward_equals_the_dense_backward_and_the_oracle(device, dim, l
     assert rel_fro(h_grad, s_grad) <= 2e-6 and worst_row_rel(h_grad, s_grad) <= TOL and rel_fro(f_grad, d_grad) <= 2e-6
     # no float atomics on either path: the same bits on every run
     assert torch.equal(run(0)[1], h_grad) and torch.equal(run(10 ** 9)[1], f_grad)
+    # the pull reads only the item rows next to a seed user (lgc_seed_mark); reading every row gives the same bits, and the
+    # marks are all taken back
+    monkeypatch.setattr(propagate, "SEED_MARKS", False)
+    assert torch.equal(run(0)[1], h_grad)
+    monkeypatch.setattr(propagate, "SEED_MARKS", True)
+    if layers > 0:
+        assert int(propagate._seed_mark_buffer(torch.device(device), n).sum()) == 0
     wr = w0.clone().requires_grad_(True)
     _, _, _, ref_loss = oracle.train_step_loss(wr, alpha, ei, ew, users, pos, neg, layers, 1e-4)
     ref_loss.backward()
