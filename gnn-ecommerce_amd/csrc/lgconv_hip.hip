@@ -350,13 +350,9 @@ __device__ __forceinline__ void rows_body(const SpmmArgs &p, int64_t block) {
 
 // Long rows: one wavefront per chunk.  Lane group g takes entries begin+g, begin+g+G, ...;
 // the G group sums are then added in group order by lane group 0.
-template <int VEC, bool FILTER = false>
-__device__ __forceinline__ void chunks_body(const SpmmArgs &p, const lgc_chunk *__restrict__ chunks, int32_t n_chunks,
-                                            float *__restrict__ partials, int64_t block) {
+template <int VEC, bool FILTER = false, bool SCREEN = false>
+__device__ __forceinline__ void chunk_core(const SpmmArgs &p, const lgc_chunk ch, float *__restrict__ partials) {
     const int lane = threadIdx.x & (kWave - 1);
-    const int64_t wave = block * (kBlock / kWave) + (threadIdx.x / kWave);
-    if (wave >= n_chunks) return;  // wave-uniform
-    const lgc_chunk ch = chunks[wave];
     const int groups = kWave / p.lpr;
     const int g = lane / p.lpr;
     const int l = lane - g * p.lpr;
@@ -365,9 +361,33 @@ __device__ __forceinline__ void chunks_body(const SpmmArgs &p, const lgc_chunk *
 
     Acc<VEC> acc;
     acc.zero();
-    bool unmarked = false;   // wave-uniform: the chunk's row has no seed among its columns -> a zero partial / zero row
-    if constexpr (FILTER) unmarked = p.row_mark != nullptr && p.row_mark[ch.row] == 0;
-    if (active && !unmarked) {
+    if constexpr (SCREEN) {
+        // a marked chunk of a seeded pull: 64 entries and their flags per round trip, then only the flagged entries (a few
+        // per chunk) are gathered -- by the lane group that owns them in the plain order (entry k belongs to group
+        // (k - begin) % groups, groups are added up in group order below), so the sums have the bits of the full scan:
+        // an unflagged entry adds val * 0 there
+        const lgc_entry *__restrict__ ent = p.entries;
+        for (int32_t base = ch.begin; base < ch.end; base += kWave) {
+            const int32_t k = base + lane;
+            lgc_entry e = {0, 0.0f};
+            bool f = false;
+            if (k < ch.end) {
+                e = ent[k];
+                f = p.col_flag[e.col] != 0;
+            }
+            unsigned long long m = __ballot(f);
+            while (m != 0) {   // wave-uniform
+                const int j = __builtin_ctzll(m);
+                m &= m - 1;
+                const int32_t col = __shfl(e.col, j);
+                const float val = __shfl(e.val, j);
+                if (active && g == (base + j - ch.begin) % groups) {
+                    const Acc<VEC> x = load_row<VEC>(p.x + c0 + (int64_t)p.col_slot[col] * p.x_stride);
+                    mul_add<VEC>(acc, val, x);
+                }
+            }
+        }
+    } else if (active) {
         const float *xb = p.x + c0;
         const lgc_entry *__restrict__ ent = p.entries;
         int32_t k = ch.begin + g;
@@ -413,6 +433,51 @@ __device__ __forceinline__ void chunks_body(const SpmmArgs &p, const lgc_chunk *
         rv.zero();
         if (p.r != nullptr) rv = load_row<VEC>(p.r + (int64_t)ch.row * p.r_stride + c0);
         finish_row<VEC, SpmmArgs>(p, ch.row, c0, acc, rv);
+    }
+}
+
+template <int VEC, bool FILTER = false>
+__device__ __forceinline__ void chunks_body(const SpmmArgs &p, const lgc_chunk *__restrict__ chunks, int32_t n_chunks,
+                                            float *__restrict__ partials, int64_t block) {
+    const int64_t wave = block * (kBlock / kWave) + (threadIdx.x / kWave);
+    if (wave >= n_chunks) return;  // wave-uniform
+    chunk_core<VEC, FILTER>(p, chunks[wave], partials);
+}
+
+// The chunk part of a seeded pull with row marks (lgc_seed_pull, row_mark != NULL): a wavefront screens kScreen chunks at
+// once -- lane l reads chunk l's descriptor and its row's mark --, writes the zero partial (or zero row) of each unmarked
+// one as a whole line and then works through the marked ones, all lanes on one chunk at a time.  One wavefront per chunk spent three
+// dependent loads on each of 60 k chunks to find the 11 % worth reading (100 us per training step).
+constexpr int kScreen = 16;
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_seed_pull_chunks(SpmmArgs p, const lgc_chunk *__restrict__ chunks, int32_t n_chunks,
+                                                            float *__restrict__ partials) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x / kWave);
+    // lane l looks at chunk l * n_waves + wave: the chunks of one long (hence surely marked) row go to different wavefronts
+    const int64_t n_waves = ((int64_t)n_chunks + kScreen - 1) / kScreen;
+    const int64_t c = (int64_t)lane * n_waves + wave;
+    const bool valid = lane < kScreen && wave < n_waves && c < n_chunks;
+    lgc_chunk ch = {0, 0, 0, -1};
+    bool marked = false;
+    if (valid) {
+        ch = chunks[c];
+        marked = p.row_mark[ch.row] != 0;
+    }
+    unsigned long long zero = __ballot(valid && !marked);   // no seed among the row's columns: zeros, unread --
+    while (zero != 0) {                                      // one whole-line store per chunk by all lanes
+        const int j = __builtin_ctzll(zero);
+        zero &= zero - 1;
+        const int row = __shfl(ch.row, j), slot = __shfl(ch.slot, j);
+        float *dst = slot >= 0 ? partials + (int64_t)slot * p.dim : p.y + (int64_t)row * p.y_stride;
+        for (int i = lane; i < p.dim; i += kWave) dst[i] = 0.0f;
+    }
+    unsigned long long todo = __ballot(marked);
+    while (todo != 0) {   // wave-uniform
+        const int j = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const lgc_chunk cj = {__shfl(ch.row, j), __shfl(ch.begin, j), __shfl(ch.end, j), __shfl(ch.slot, j)};
+        chunk_core<VEC, true, true>(p, cj, partials);
     }
 }
 
@@ -1305,12 +1370,13 @@ __global__ __launch_bounds__(kBlock) void k_segment_sum(const int64_t *__restric
 __global__ void k_seed_mark(const int32_t *__restrict__ rowptr, const lgc_entry *__restrict__ entries, int32_t row_begin,
                             int32_t row_end, const int64_t *__restrict__ seed_rows, int64_t n_seed, uint8_t *__restrict__ mark,
                             int64_t mark_len, uint8_t value) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t t = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;   // one wavefront per listed row
     if (t >= n_seed) return;
     const int64_t row = seed_rows[t];
     if (row < row_begin || row >= row_end) return;
     if (t > 0 && seed_rows[t - 1] == row) return;        // sorted lists: a repeated row is marked once
-    for (int32_t k = rowptr[row]; k < rowptr[row + 1]; ++k) {
+    for (int32_t k = rowptr[row] + lane; k < rowptr[row + 1]; k += kWave) {
         const int32_t c = entries[k].col;
         if (c >= 0 && c < mark_len) mark[c] = value;
     }
@@ -2482,7 +2548,7 @@ int lgc_seed_mark(const int32_t *rowptr, const lgc_entry *entries, int32_t row_b
     if (n_seed < 0 || row_begin < 0 || row_end < row_begin || mark_len < 0 || value < 0 || value > 255) return LGC_E_INVAL;
     if (n_seed == 0) return 0;
     if (!rowptr || !entries || !seed_rows || !mark) return LGC_E_INVAL;
-    hipLaunchKernelGGL(k_seed_mark, dim3(ceil_div(n_seed, (int64_t)kBlock)), dim3(kBlock), 0, as_stream(stream_), rowptr, entries,
+    hipLaunchKernelGGL(k_seed_mark, dim3(ceil_div(n_seed, (int64_t)(kBlock / kWave))), dim3(kBlock), 0, as_stream(stream_), rowptr, entries,
                        row_begin, row_end, seed_rows, n_seed, mark, mark_len, (uint8_t)value);
     return (int)hipGetLastError();
 }
@@ -2508,9 +2574,15 @@ int lgc_seed_pull(const int32_t *rowptr, const lgc_entry *entries, int32_t row_b
         const int64_t n_rows = (int64_t)row_end - row_begin;
         const int row_blocks = n_rows > 0 ? ceil_div(ceil_div(n_rows, rows_per_wave), waves_per_block) : 0;
         const int chunk_blocks = n_chunks > 0 ? ceil_div(n_chunks, waves_per_block) : 0;
-        if (row_blocks + chunk_blocks > 0)
+        if (row_mark != nullptr && n_chunks > 0) {
+            if (row_blocks > 0)
+                hipLaunchKernelGGL((k_spmm_hop<V, true>), dim3(row_blocks), dim3(kBlock), 0, stream, p, chunks, 0, partials, 0);
+            hipLaunchKernelGGL((k_seed_pull_chunks<V>), dim3(ceil_div(ceil_div(n_chunks, kScreen), waves_per_block)), dim3(kBlock), 0,
+                               stream, p, chunks, n_chunks, partials);
+        } else if (row_blocks + chunk_blocks > 0) {
             hipLaunchKernelGGL((k_spmm_hop<V, true>), dim3(row_blocks + chunk_blocks), dim3(kBlock), 0, stream, p, chunks, n_chunks,
                                partials, chunk_blocks);
+        }
         if (n_multi > 0)
             hipLaunchKernelGGL((k_spmm_combine<V>), dim3(ceil_div(n_multi, waves_per_block)), dim3(kBlock), 0, stream, p, multi,
                                n_multi, partials);
