@@ -31,6 +31,7 @@ from . import _native
 # are cut into chunks of about CHUNK_LEN entries, one wavefront each.
 SHORT_MAX = int(os.environ.get("LGCN_SHORT_MAX", "32"))
 CHUNK_LEN = int(os.environ.get("LGCN_CHUNK_LEN", "256"))
+USER_CHUNK_LEN = int(os.environ.get("LGCN_USER_CHUNK_LEN", "4096"))   # the user half of a user|item graph (PropGraph.halves)
 # Rows of up to 32 entries go through the tiled kernels (lgc_spmm_tiles) in width classes of 8 / 16 / 32 entries.
 TILE_WIDTHS = (8, 16, 32)
 USE_TILES = os.environ.get("LGCN_TILES", "1") == "1"
@@ -538,10 +539,13 @@ class PropGraph:
         if got is None:
             op = self.transpose_op if transpose else self.forward_op
             # every column of a user row is an item and vice versa: each half may sweep the other side's range
-            got = tuple(Operator.build(op.n_rows, op.rowptr, op.entries, lo, hi, self.short_max, self.chunk_len,
-                                       sweep_cols=cols)
-                        for (lo, hi), cols in (((0, self.split), (self.split, self.num_nodes)),
-                                               ((self.split, self.num_nodes), (0, self.split))))
+            # user rows above short_max are few (12 k of 1.6 M on the cosmetics graph, the longest 2.6 k entries): one
+            # chunk each, started first, finishes inside the launch and spares the half its combine launch (3 x 4.6 us of
+            # a 1.6 ms step); the item rows (up to 87 k entries) keep the short chunks
+            got = tuple(Operator.build(op.n_rows, op.rowptr, op.entries, lo, hi, self.short_max, chunk, sweep_cols=cols)
+                        for (lo, hi), cols, chunk in (((0, self.split), (self.split, self.num_nodes),
+                                                       max(self.chunk_len, USER_CHUNK_LEN)),
+                                                      ((self.split, self.num_nodes), (0, self.split), self.chunk_len)))
             self._halves[transpose] = got
         return got
 
