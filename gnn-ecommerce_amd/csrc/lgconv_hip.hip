@@ -2612,12 +2612,24 @@ int lgc_lincomb(float *y, int64_t y_stride, const float *const *src, const int64
 int lgc_adam_step(float *w, const float *g, float *m, float *v, int64_t n, float one_minus_beta1, float beta2,
                   float one_minus_beta2, float eps, float step_size, float bias_correction2_sqrt, void *stream_) {
     if (!w || !g || !m || !v || n < 0 || !(bias_correction2_sqrt > 0.0f)) return LGC_E_INVAL;
-    if (!aligned_to(w, 16) || !aligned_to(g, 16) || !aligned_to(m, 16) || !aligned_to(v, 16)) return LGC_E_ALIGN;
+    // dword-aligned, and all four at the same offset inside a 16-byte line (a row range of same-shaped tables whose rows
+    // are not whole float4s, e.g. rows [lo, hi) of a [N, 90] table): the first elements up to the line are done one by one
+    const uintptr_t mis = reinterpret_cast<uintptr_t>(w) & 15;
+    if ((mis & 3) != 0 || (reinterpret_cast<uintptr_t>(g) & 15) != mis || (reinterpret_cast<uintptr_t>(m) & 15) != mis ||
+        (reinterpret_cast<uintptr_t>(v) & 15) != mis)
+        return LGC_E_ALIGN;
     if (n == 0) return 0;
+    hipStream_t stream = as_stream(stream_);
+    const int64_t head = std::min<int64_t>(n, (int64_t)((16 - mis) & 15) / 4);
+    if (head > 0)
+        hipLaunchKernelGGL(k_adam, dim3(1), dim3(kBlock), 0, stream, w, g, m, v, (int64_t)0, head, beta2, one_minus_beta1,
+                           one_minus_beta2, eps, step_size, bias_correction2_sqrt);
+    w += head; g += head; m += head; v += head; n -= head;
+    if (n == 0) return (int)hipGetLastError();
     const int64_t n4 = n / 4;
     const int64_t blocks = std::max<int64_t>(ceil_div(n4, (int64_t)kBlock * 2), 1);
     if (blocks >= INT32_MAX) return LGC_E_RANGE;
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream_), w, g, m, v, n4, n, beta2,
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(kBlock), 0, stream, w, g, m, v, n4, n, beta2,
                        one_minus_beta1, one_minus_beta2, eps, step_size, bias_correction2_sqrt);
     return (int)hipGetLastError();
 }

@@ -22,7 +22,7 @@ from . import _native
 from .graph import get_graph
 from .lgconv import LGConv
 from .propagate import (TOPK_MAX, RegHook, SeenLists, mask_topk, pair_dot, propagate_sum, regularization_through,
-                        scores_from_table)
+                        routable_index, scores_from_table)
 
 __all__ = ["LightGCN", "BPRLoss", "LGConv", "regularization_loss"]
 
@@ -216,7 +216,8 @@ def regularization_loss(init_embed: Tensor, batch_size: int, batch_usr: Tensor, 
     dense two-node path, the graph already consumed) this is upstream's expression on plain torch ops."""
     hook = getattr(init_embed, "_lgcn_reg_hook", None)
     if (hook is not None and not hook.spent and hook.token is not None and hook.weight is init_embed
-            and torch.is_grad_enabled() and init_embed.is_cuda):
+            and torch.is_grad_enabled() and init_embed.is_cuda
+            and all(routable_index(t) for t in (batch_usr, batch_pos, batch_neg))):
         return regularization_through(hook, batch_size, batch_usr, batch_pos, batch_neg, decay)
     reg_loss = (1 / 2) * (init_embed[batch_usr].norm().pow(2) + init_embed[batch_pos].norm().pow(2)
                           + init_embed[batch_neg].norm().pow(2)) / batch_size

@@ -32,6 +32,7 @@ from torch import Tensor
 
 from . import _native
 from .graph import CHUNK_LEN, SHORT_MAX, Operator, PropGraph, build_row_plan
+from .propagate import DeviceOps
 
 
 ITEM_SHORT_MAX = int(os.environ.get("LGCN_ITEM_SHORT_MAX", "32"))   # 8 / 16 / 32: 114 / 113 / 112 us per hop at world 8, 202 -> 190 at world 4
@@ -67,8 +68,9 @@ def check_bipartite(edge_index: Tensor, n_users: int, n_items: int) -> None:
         raise ValueError("partitioned propagation needs a bipartite user|item edge list (ids < n_users are users)")
 
 
-class HipOps:
-    """The shipped implementation of the arithmetic: HIP kernels through the C ABI."""
+class HipOps(DeviceOps):
+    """The shipped implementation of the arithmetic: HIP kernels through the C ABI (propagate.DeviceOps) plus the graph
+    builders of a partition."""
 
     def build(self, edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int, normalize: bool,
               keep_edge_values: bool = False) -> PropGraph:
@@ -82,11 +84,8 @@ class HipOps:
         return Operator.build(op.n_rows, op.rowptr, op.entries, row_begin, row_end, short_max, CHUNK_LEN,
                               sweep_cols=sweep_cols)
 
-    def apply(self, op: Operator, x: Tensor, out: Tensor, a: float, r: Optional[Tensor], b: float) -> None:
+    def apply(self, op: Operator, x: Tensor, out: Tensor, a: float = 1.0, r: Optional[Tensor] = None, b: float = 0.0) -> None:
         op.apply(x, out, a=a, r=r, b=b)
-
-    def lincomb(self, y: Tensor, terms) -> None:
-        _native.lincomb(y, terms)
 
 
 class PartitionedPropagator:
@@ -194,8 +193,13 @@ class PartitionedPropagator:
             self._table_cache[key] = got
         return got
 
+    def owned_row_ranges(self) -> List[Tuple[int, int]]:
+        """The rows of an [N, D] table this rank owns: its user range and the (replicated) item block -- what
+        ``optim.Adam(row_ranges=...)`` updates on this rank."""
+        return [(self.u0, self.u1), (self.n_users, self.num_nodes)]
+
     def propagate_sum(self, x0: Tensor, alphas: Sequence[float], transpose: bool = False,
-                      zero_foreign_rows: bool = False) -> Tensor:
+                      zero_foreign_rows: bool = False, final_rows: Optional[Tensor] = None) -> Tensor:
         """sum_l alpha_l A^l x0 on this rank's rows (own users + all items), in the bipartite evaluation of
         propagate.bipartite_sum: with x_l = A^l x0,
             x_l[items]  = all-reduce( item step over OWN users of x_{l-1} )          l = 1 .. K
@@ -206,7 +210,9 @@ class PartitionedPropagator:
         The all-reduce of layer l is started right after its item step and waited for only where x_l[items] is first
         read -- the user step of layer l+1 (or the final sums) -- i.e. it is in flight across one user step and the next
         item step.  ``transpose``: the same with A^T (the backward pass).  ``zero_foreign_rows``: other ranks' user rows
-        of the result are zero instead of undefined."""
+        of the result are zero instead of undefined.  ``final_rows`` (int64 node ids): the caller will only read these
+        user rows of the result (plus the item block) -- the last user step is computed for them only (lgc_spmm_rows),
+        as in propagate.bipartite_sum: a training step scores a few thousand pairs."""
         from . import propagate
         k = len(alphas) - 1
         if k == 0:
@@ -232,7 +238,10 @@ class PartitionedPropagator:
                 self.ops.apply(user_op, prev, cur, 1.0, None, 0.0)
             else:
                 self._lincomb(mix[nu:], [(alphas[l], tables[l - 1][nu:]) for l in range(1, k + 1)])
-                self.ops.apply(user_op, mix, out, 1.0, x0, alphas[0])
+                if final_rows is None:
+                    self.ops.apply(user_op, mix, out, 1.0, x0, alphas[0])
+                else:
+                    self.ops.apply_rows(user_op, final_rows, mix, out, 1.0, x0, alphas[0])
                 self._finish_items(pending[k])
                 self._lincomb(out[nu:], [(alphas[l], tables[l][nu:]) for l in range(0, k + 1)])
         if log is not None:
@@ -241,6 +250,22 @@ class PartitionedPropagator:
             marks.append(ev)
             log.extend(zip(marks[:-1], marks[1:]))
         return out
+
+    def seeded_transpose_sum(self, rows: Tensor, vals: Tensor, alphas: Sequence[float], extra=None,
+                             zero_rows=None) -> Tensor:
+        """sum_l alpha_l (A^T)^l g on this rank's rows for a gradient g given by its non-zero rows (own users + items; the
+        item rows complete, i.e. already summed over the ranks): propagate.seeded_sum on the rank's local halves of A^T,
+        every hop's item block all-reduced like the forward pass."""
+        from . import propagate
+        user_t, item_t = self._transposed_ops()
+
+        def exchange(block: Tensor):
+            if self.world == 1:
+                return None
+            return _ExchangeHandle(dist.all_reduce(block, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+        return propagate.seeded_sum(user_t, item_t, self.user_op, self.n_users, rows, vals, alphas, self.num_nodes, extra,
+                                    ops=self.ops, exchange=exchange, zero_rows=zero_rows)
 
     def gather_users(self, table: Tensor) -> Tensor:
         """Fill every rank's user rows of ``table`` from their owners (all ranks end with the full table): ONE
@@ -257,6 +282,17 @@ class PartitionedPropagator:
             if owner != self.rank and hi > lo:
                 table[lo:hi] = everyone[owner * longest: owner * longest + (hi - lo)]
         return table
+
+
+class _ExchangeHandle:
+    """What PartitionedPropagator hands propagate.seeded_sum for one item block: the all-reduce in flight."""
+
+    def __init__(self, work):
+        self.work = work
+
+    def wait(self) -> None:
+        if self.work is not None:
+            self.work.wait()
 
 
 class _PartitionedSum(torch.autograd.Function):
@@ -292,8 +328,65 @@ def own_pairs(pp: PartitionedPropagator, edge_label_index: Tensor) -> Tensor:
     return (u >= pp.u0) & (u < pp.u1)
 
 
+# The seeded scoring node (below) is used when the batch is far smaller than the table, like propagate.scores_from_table
+SEEDED_STEP = os.environ.get("LGCN_PARTITION_SEEDED", "1") == "1"
+
+
+class _PartitionedScores(torch.autograd.Function):
+    """Scores of ONE global batch on a rank of a partition, as one autograd node -- the partitioned form of
+    propagate._ScoresFromTable (src/lightgcn.py:121-125 behind src/train_lightgcn.py:138):
+
+    forward   propagate on the partition, the last user step for the batch's own users only (lgc_spmm_rows), then
+              lgc_pair_dot for all 2B pairs with FIXED shapes: a triple whose user another rank owns is scored against
+              an own user row standing in for it (the id clamped into [u0, u1)) and masked out by the caller, so that no
+              step needs the host to know how many triples a rank owns (no sync, no dynamic shapes);
+    backward  the seed of the transposed propagation: user rows from this rank's own pairs; item rows from EVERY rank's
+              pairs -- d score / d out[item] = gs * out[user] is known to the user's owner only, so the [2B, D] table of
+              those products (zero rows for foreign pairs) is summed over the ranks: 0.5 MB instead of the 14 MB item
+              block of a dense gradient; then propagate.seeded_sum on the rank's local halves of A^T with the per-hop
+              item-block exchange.  The regulariser's rows (own users of the batch, all items of the batch) are added
+              by the same node.  Result: the gradient of the rows this rank owns; other ranks' user rows are left
+              unwritten unless ``zero_foreign``.
+    Second output: the zero-valued token a regulariser routes its gradient through (propagate.RegHook's mechanism)."""
+
+    @staticmethod
+    def forward(ctx, w: Tensor, pp: "PartitionedPropagator", alphas: tuple, users: Tensor, pos: Tensor, neg: Tensor,
+                reg_scale: float, zero_foreign: bool):
+        ops = pp.ops
+        mine = (users >= pp.u0) & (users < pp.u1)
+        uc = users.clamp(pp.u0, pp.u1 - 1)                       # foreign users: any own row stands in, masked out later
+        idx0, idx1 = torch.cat([uc, uc]), torch.cat([pos, neg])
+        emb = pp.propagate_sum(w.detach(), alphas, final_rows=uc)
+        scores = ops.pair_scores(emb, idx0, idx1)
+        ctx.save_for_backward(emb[idx0], emb[idx1], idx0, idx1, torch.cat([mine, mine]), w)
+        ctx.pp, ctx.alphas, ctx.reg_scale, ctx.zero_foreign = pp, alphas, reg_scale, zero_foreign
+        ctx.set_materialize_grads(False)
+        return scores, torch.zeros((), dtype=torch.float32, device=w.device)
+
+    @staticmethod
+    def backward(ctx, grad_scores: Optional[Tensor], grad_token: Optional[Tensor]):
+        e0, e1, idx0, idx1, mine2, w = ctx.saved_tensors
+        pp = ctx.pp
+        if grad_scores is None:
+            grad_scores = torch.zeros(idx0.numel(), dtype=torch.float32, device=e0.device)
+        gs = torch.where(mine2, grad_scores, torch.zeros_like(grad_scores)).unsqueeze(1)
+        item_vals = (gs * e0).contiguous()                       # d / d out[item of pair m]: non-zero on the user's owner only
+        if pp.world > 1:
+            dist.all_reduce(item_vals, op=dist.ReduceOp.SUM, group=pp.group)
+        rows = torch.cat([idx0, idx1])
+        vals = torch.cat([gs * e1, item_vals])
+        extra = []
+        if grad_token is not None and ctx.reg_scale != 0.0:
+            wd = w.detach()
+            b = idx0.numel() // 2                                # idx0 = [u | u], idx1 = [pos | neg]: each row once
+            own = mine2[:b].to(wd.dtype).unsqueeze(1)            # a user row's regulariser term belongs to its owner
+            extra = [(torch.cat([idx0[:b], idx1]), torch.cat([wd[idx0[:b]] * own, wd[idx1]]) * grad_token, ctx.reg_scale)]
+        zero = [(0, pp.u0), (pp.u1, pp.n_users)] if ctx.zero_foreign else None
+        return pp.seeded_transpose_sum(rows, vals, ctx.alphas, extra, zero), None, None, None, None, None, None, None
+
+
 def partitioned_bpr_loss(pp: PartitionedPropagator, weight: Tensor, alphas: Sequence[float], users: Tensor,
-                         pos: Tensor, neg: Tensor, decay: float, pair_scores=None):
+                         pos: Tensor, neg: Tensor, decay: float, pair_scores=None, zero_foreign_rows: bool = True):
     """The loss of src/train_lightgcn.py:137-144 (bpr * size + reg) for one GLOBAL batch given to every rank.
 
     Each rank scores the triples of its own users and returns the LOCAL part of the loss whose sum over
@@ -301,24 +394,48 @@ def partitioned_bpr_loss(pp: PartitionedPropagator, weight: Tensor, alphas: Sequ
     for the rows this rank owns (own users, all items -- item rows identical on every rank).  The
     regulariser's item terms are evaluated on every rank (replicated parameters), its user terms on the
     owner only.  Returns (local_loss, global_bpr, global_reg) -- the two globals detached, for logging.
+
+    With a batch far smaller than the table (the training case) the step is one seeded node (_PartitionedScores):
+    scored-rows-only last user step, seeded backward on the rank's halves of A^T, the regulariser's gradient inside the
+    same node, no dense [N, D] gradient anywhere and no host sync.  ``zero_foreign_rows=False`` additionally leaves the
+    user rows other ranks own unwritten in ``weight.grad`` (a caller that updates only ``pp.owned_row_ranges()``, like
+    ``optim.Adam(row_ranges=...)``, never reads them).  Otherwise the dense path below.
     """
-    if pair_scores is None:
-        from .propagate import pair_dot as pair_scores
     size = users.numel()
-    out = partitioned_embedding(pp, weight, alphas)
-    mine = (users >= pp.u0) & (users < pp.u1)
-    u, p, n = users[mine], pos[mine], neg[mine]
-    # a rank without own triples must still take part in the collectives of the backward pass
-    bpr_local = out[:1].sum() * 0.0
-    if u.numel():
-        scores = pair_scores(out, torch.stack((torch.cat([u, u]), torch.cat([p, n]))))
-        m = u.numel()
-        bpr_local = -torch.nn.functional.logsigmoid(scores[:m] - scores[m:]).sum() / size
-    reg_users = 0.5 * weight[u].norm().pow(2) / size * decay
-    reg_items = 0.5 * (weight[pos].norm().pow(2) + weight[neg].norm().pow(2)) / size * decay
-    # item terms are computed identically on every rank: scale so that backward() leaves the reference's
-    # gradient in the item rows exactly once, while the reported global value is still their plain sum
-    local = bpr_local + reg_users + reg_items
+    from . import propagate
+    seeded = (SEEDED_STEP and propagate.SPARSE_BACKWARD and pair_scores is None and hasattr(pp.ops, "seed_pull")
+              and pp.u1 > pp.u0 and torch.is_grad_enabled() and weight.requires_grad
+              and len(alphas) - 1 <= _native.MAX_TERMS - 1
+              and 2 * size * propagate.SEED_ROWS_FACTOR <= weight.size(0))
+    if seeded:
+        alphas = tuple(float(a) for a in alphas)
+        scores, token = _PartitionedScores.apply(weight, pp, alphas, users, pos, neg, float(decay) / float(size),
+                                                 zero_foreign_rows)
+        mine = (users >= pp.u0) & (users < pp.u1)
+        diff = torch.where(mine, scores[:size] - scores[size:], torch.zeros_like(scores[:size]))
+        bpr_local = -(torch.nn.functional.logsigmoid(diff) * mine.to(scores.dtype)).sum() / size
+        wd = weight.detach()
+        uc = users.clamp(pp.u0, pp.u1 - 1)
+        reg_users = 0.5 * (wd[uc] * mine.to(wd.dtype).unsqueeze(1)).norm().pow(2) / size * decay
+        reg_items = 0.5 * (wd[pos].norm().pow(2) + wd[neg].norm().pow(2)) / size * decay
+        local = bpr_local + propagate._RegThroughHook.apply(token, reg_users + reg_items)
+    else:
+        if pair_scores is None:
+            from .propagate import pair_dot as pair_scores
+        out = partitioned_embedding(pp, weight, alphas)
+        mine = (users >= pp.u0) & (users < pp.u1)
+        u, p, n = users[mine], pos[mine], neg[mine]
+        # a rank without own triples must still take part in the collectives of the backward pass
+        bpr_local = out[:1].sum() * 0.0
+        if u.numel():
+            scores = pair_scores(out, torch.stack((torch.cat([u, u]), torch.cat([p, n]))))
+            m = u.numel()
+            bpr_local = -torch.nn.functional.logsigmoid(scores[:m] - scores[m:]).sum() / size
+        reg_users = 0.5 * weight[u].norm().pow(2) / size * decay
+        reg_items = 0.5 * (weight[pos].norm().pow(2) + weight[neg].norm().pow(2)) / size * decay
+        # item terms are computed identically on every rank: scale so that backward() leaves the reference's
+        # gradient in the item rows exactly once, while the reported global value is still their plain sum
+        local = bpr_local + reg_users + reg_items
     with torch.no_grad():
         part = torch.stack([bpr_local.detach(), reg_users.detach()])
         if pp.world > 1:

@@ -289,6 +289,19 @@ def segment_sum(key_sorted: Tensor, dest: Tensor, vals: Tensor, out: Tensor, sca
     """out[dest[t]] (+)= scale * (sum of vals over the run of equal keys that starts at t), for every run head t with
     dest[t] >= 0: lgc_segment_sum -- one lane group per destination row, fixed order, no atomics."""
     lib = _native.load()
+    _native.require_device(out, "segment_sum: out")
+    if out.dtype != torch.float32 or out.dim() != 2 or out.stride(1) != 1:
+        raise TypeError("segment_sum: out must be a 2-D fp32 tensor with unit inner stride")
+    m = key_sorted.numel()
+    for name, t in (("key_sorted", key_sorted), ("dest", dest)):
+        # raw pointers go to the kernel: a host tensor or int32 data read as int64 would be a GPU fault or garbage keys
+        if t.dtype != torch.int64 or t.dim() != 1 or t.numel() != m or not t.is_contiguous() or t.device != out.device:
+            raise TypeError(f"segment_sum: {name} must be a contiguous int64 vector of {m} entries on {out.device}, got "
+                            f"{t.dtype} {tuple(t.shape)} on {t.device}")
+    if (vals.dtype != torch.float32 or vals.dim() != 2 or vals.shape != (m, out.size(1)) or not vals.is_contiguous()
+            or vals.device != out.device):
+        raise TypeError(f"segment_sum: vals must be a contiguous fp32 [{m}, {out.size(1)}] tensor on {out.device}, got "
+                        f"{vals.dtype} {tuple(vals.shape)} on {vals.device}")
     with torch.cuda.device(out.device):
         code = lib.lgc_segment_sum(_native.ptr(key_sorted), _native.ptr(dest), _native.ptr(vals), key_sorted.numel(), float(scale),
                                    _native.ptr(out), out.stride(0), out.size(0), out.size(1), int(accumulate),
@@ -333,13 +346,21 @@ def _seed_mark(op: Operator, rows_sorted: Tensor, mark: Tensor, value: int) -> N
 _seed_maps = {}
 
 
+def _scratch_key(device: torch.device):
+    """Scratch that must be all zero between uses is owned by one (device, stream) pair: the set / pull / clear sequence
+    of a backward pass is ordered on ITS stream only, so two backward passes on different streams (two models, a
+    DataParallel-style host loop) each get their own buffers instead of reading or clearing each other's flags."""
+    return (device, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+
+
 def _seed_map_buffers(device: torch.device, n_cols: int):
-    """Per device: a byte flag and an int32 slot per column, flags all zero between uses (the pull reads a slot only
-    where the flag is set; the flags of a step's seeds are cleared again right after the pull)."""
-    got = _seed_maps.get(device)
+    """Per (device, stream): a byte flag and an int32 slot per column, flags all zero between uses (the pull reads a
+    slot only where the flag is set; the flags of a step's seeds are cleared again right after the pull)."""
+    key = _scratch_key(device)
+    got = _seed_maps.get(key)
     if got is None or got[0].numel() < n_cols + 1:
         got = (torch.zeros(n_cols + 1, dtype=torch.uint8, device=device), torch.empty(n_cols + 1, dtype=torch.int32, device=device))
-        _seed_maps[device] = got
+        _seed_maps[key] = got
     return got
 
 
@@ -349,16 +370,71 @@ SEED_MARKS = os.environ.get("LGCN_SEED_MARKS", "1") == "1"
 
 
 def _seed_mark_buffer(device: torch.device, n_rows: int) -> Tensor:
-    """Per device: one byte per table row, all zero between uses."""
-    got = _seed_marks.get(device)
+    """Per (device, stream): one byte per table row, all zero between uses."""
+    key = _scratch_key(device)
+    got = _seed_marks.get(key)
     if got is None or got.numel() < n_rows:
         got = torch.zeros(n_rows, dtype=torch.uint8, device=device)
-        _seed_marks[device] = got
+        _seed_marks[key] = got
     return got
+
+
+class DeviceOps:
+    """The launches the seeded backward and the partitioned path are written against: one method = one (or a few)
+    launches through the C ABI on the current stream.  ``partition.HipOps`` is this plus the graph builders; the CPU ranks
+    of tests/test_partition_gloo.py substitute a test double with the same methods (tests/cpu_ops.py) -- the product
+    ships this implementation only."""
+
+    def apply(self, op: Operator, x: Tensor, out: Tensor, a: float = 1.0, r: Optional[Tensor] = None, b: float = 0.0) -> None:
+        op.apply(x, out, a=a, r=r, b=b)
+
+    def apply_rows(self, op: Operator, rows: Tensor, x: Tensor, out: Tensor, a: float = 1.0, r: Optional[Tensor] = None,
+                   b: float = 0.0) -> None:
+        apply_rows(op, rows, x, out, a=a, r=r, b=b)
+
+    def lincomb(self, y: Tensor, terms) -> None:
+        _native.lincomb(y, terms)
+
+    def segment_sum(self, key_sorted: Tensor, dest: Tensor, vals: Tensor, out: Tensor, scale: float = 1.0,
+                    accumulate: bool = False) -> None:
+        segment_sum(key_sorted, dest, vals, out, scale=scale, accumulate=accumulate)
+
+    def seed_pull(self, op: Operator, flag: Tensor, slot: Tensor, seed_vals: Tensor, out: Tensor, mark: Optional[Tensor]) -> None:
+        _seed_pull(op, flag, slot, seed_vals, out, mark)
+
+    def seed_mark(self, op: Operator, rows_sorted: Tensor, mark: Tensor, value: int) -> None:
+        _seed_mark(op, rows_sorted, mark, value)
+
+    def pair_scores(self, emb: Tensor, idx0: Tensor, idx1: Tensor) -> Tensor:
+        """scores[m] = <emb[idx0[m]], emb[idx1[m]]> (lgc_pair_dot; out-of-range pairs score NaN and raise later)."""
+        lib = _native.load()
+        scores = torch.empty(idx0.numel(), dtype=torch.float32, device=emb.device)
+        with torch.cuda.device(emb.device):
+            code = lib.lgc_pair_dot(_native.ptr(emb), emb.stride(0), emb.size(1), emb.size(0), _native.ptr(idx0),
+                                    _native.ptr(idx1), idx0.numel(), _native.ptr(scores), _native.ptr(_status(emb.device)),
+                                    _native.stream_of(emb.device))
+        _native.check(code, "lgc_pair_dot")
+        _snapshot_status(emb.device)
+        return scores
+
+    def scratch_table(self, like: Tensor) -> Tensor:
+        return scratch_table(like)
+
+
+DEVICE_OPS = DeviceOps()
 
 
 def seeded_transpose_sum(graph: PropGraph, rows: Tensor, vals: Tensor, alphas: Sequence[float], n: int,
                          extra: Optional[Sequence] = None) -> Tensor:
+    """sum_l alpha_l (A^T)^l g for a gradient g given by its non-zero rows, on one device: ``seeded_sum`` with the
+    graph's own operator halves and no exchange."""
+    user_t, item_t = graph.halves(True)
+    return seeded_sum(user_t, item_t, graph.halves(False)[0], graph.split, rows, vals, alphas, n, extra)
+
+
+def seeded_sum(user_t, item_t, user_fwd, split: int, rows: Tensor, vals: Tensor, alphas: Sequence[float], n: int,
+               extra: Optional[Sequence] = None, ops: Optional[DeviceOps] = None, exchange=None,
+               zero_rows: Optional[Sequence] = None) -> Tensor:
     """sum_l alpha_l (A^T)^l g for a gradient g given by its non-zero rows (``rows`` int64, repeats add up; ``vals`` [len, D])
     on a user|item graph -- what ``_PropagateSum.backward`` computes from a dense g, without ever forming it:
       * the seed is sorted once; repeated rows are summed in position order by lgc_segment_sum (no float atomics anywhere:
@@ -371,10 +447,17 @@ def seeded_transpose_sum(graph: PropGraph, rows: Tensor, vals: Tensor, alphas: S
         initialised, let alone zero-filled);
       * the alpha_0 g term of the user rows is added to the seed rows afterwards instead of being read as a dense
         epilogue table by the last user step.
-    ``extra``: (rows, vals, scale) triples added to the result's rows the same way -- the regulariser's gradient
-    (LightGCN.regularization_loss), which upstream's autograd materialises as three dense [N, D] tables."""
+    ``user_t`` / ``item_t``: the user-row and item-row halves of A^T; ``user_fwd``: the user-row half of A (its columns
+    name the item rows of A^T that hold a seed user).  ``extra``: (rows, vals, scale) triples added to the result's rows
+    the same way -- the regulariser's gradient (LightGCN.regularization_loss), which upstream's autograd materialises as
+    three dense [N, D] tables.
+    On a rank of a partition (partition.py) the halves are the rank's LOCAL operators -- the user rows it owns, and the
+    item rows restricted to its own users as columns -- and ``exchange(block)`` starts the sum of an item block over the
+    ranks, returning a handle whose ``wait()`` completes it (None: nothing to wait for).  The item block of layer l is
+    waited for right before the user step of layer l + 1 reads it, exactly like the forward pass.  ``zero_rows``: row
+    ranges of the result to zero-fill (the user rows other ranks own); default none."""
+    ops = ops or DEVICE_OPS
     k = len(alphas) - 1
-    split = graph.split
     dim = vals.size(1)
     dev = vals.device
     m = rows.numel()
@@ -387,57 +470,75 @@ def seeded_transpose_sum(graph: PropGraph, rows: Tensor, vals: Tensor, alphas: S
     none = torch.full_like(rows_s, -1)
     g_tab = torch.empty((n, dim), dtype=torch.float32, device=dev)         # only the item block is ever read
     g_tab[split:].zero_()
-    segment_sum(rows_s, torch.where(is_user, none, rows_s), vals_s, g_tab)                  # g[items]
+    ops.segment_sum(rows_s, torch.where(is_user, none, rows_s), vals_s, g_tab)              # g[items]
 
-    def add_extra(out: Tensor) -> Tensor:
+    def wait(work) -> None:
+        if work is not None:
+            work.wait()
+
+    def finish(out: Tensor) -> Tensor:
         for e_rows, e_vals, e_scale in (extra or ()):
             e_s, e_perm = torch.sort(e_rows, stable=True)
-            segment_sum(e_s, e_s, e_vals[e_perm].contiguous(), out, scale=e_scale, accumulate=True)
+            ops.segment_sum(e_s, e_s, e_vals[e_perm].contiguous(), out, scale=e_scale, accumulate=True)
+        return out
+
+    def new_result() -> Tensor:
+        out = torch.empty((n, dim), dtype=torch.float32, device=dev)
+        for lo, hi in (zero_rows or ()):
+            if hi > lo:
+                out[lo:hi].zero_()
         return out
 
     if k == 0:
         out = torch.zeros((n, dim), dtype=torch.float32, device=dev)
-        segment_sum(rows_s, rows_s, vals_s, out, scale=alphas[0])
-        return add_extra(out)
+        ops.segment_sum(rows_s, rows_s, vals_s, out, scale=alphas[0])
+        return finish(out)
     # compact table of the seed users: slot = position of the run's head
     gu = torch.empty((m, dim), dtype=torch.float32, device=dev)
     user_head = is_user & head
-    segment_sum(rows_s, torch.where(user_head, pos, none), vals_s, gu)
+    ops.segment_sum(rows_s, torch.where(user_head, pos, none), vals_s, gu)
     flag, slot = _seed_map_buffers(dev, split)
     fidx = torch.where(is_user, rows_s, torch.full_like(rows_s, split))    # non-users park on the spare entry `split`
     flag[fidx] = 1
     slot[torch.where(user_head, rows_s, torch.full_like(rows_s, split))] = pos.to(torch.int32)
-    user_t, item_t = graph.halves(True)
+    # Which item rows of A^T hold a seed user among their columns: row i of A^T has the columns {u : A[u, i] != 0}, so
+    # the rows to read are the columns of the seed users' rows of the FORWARD operator A (not of A^T, whose user row u
+    # lists {i : A[i, u] != 0} -- the same set only on a structurally symmetric edge list, which is never assumed).
     tables = [g_tab]
+    pending = [None] * (k + 1)                                             # exchange of x_l[items]
     out = None
     for layer in range(1, k + 1):
         with _HopSpan():
-            nxt = scratch_table(g_tab)
+            nxt = ops.scratch_table(g_tab)
             if layer == 1:
                 mark = _seed_mark_buffer(dev, n) if SEED_MARKS else None
                 try:
                     if mark is not None:                                        # the item rows next to a seed user: the only
-                        _seed_mark(user_t, rows_s, mark, 1)                     # rows the pull has to read
-                    _seed_pull(item_t, flag, slot, gu, nxt, mark)               # x_1[items] from the seed users
+                        ops.seed_mark(user_fwd, rows_s, mark, 1)                # rows the pull has to read
+                    ops.seed_pull(item_t, flag, slot, gu, nxt, mark)            # x_1[items] from the seed users
                 finally:
                     flag[fidx] = 0                                              # flags and marks are all zero between steps
                     if mark is not None:
-                        _seed_mark(user_t, rows_s, mark, 0)
+                        ops.seed_mark(user_fwd, rows_s, mark, 0)
             else:
-                item_t.apply(tables[-1], nxt)
+                ops.apply(item_t, tables[-1], nxt)
+            if exchange is not None:
+                pending[layer] = exchange(nxt[split:])
+            wait(pending[layer - 1])                                            # x_{l-1}[items] is read from here on
             if layer < k:
-                user_t.apply(tables[-1], nxt)
+                ops.apply(user_t, tables[-1], nxt)
                 tables.append(nxt)
             else:
                 tables.append(nxt)
-                out = torch.empty((n, dim), dtype=torch.float32, device=dev)
-                mix = scratch_table(g_tab)
-                _native.lincomb(mix[split:], [(alphas[l], tables[l - 1][split:]) for l in range(1, k + 1)])
-                _native.lincomb(out[split:], [(alphas[l], tables[l][split:]) for l in range(0, k + 1)])
-                user_t.apply(mix, out, a=1.0)
+                out = new_result()
+                mix = ops.scratch_table(g_tab)
+                ops.lincomb(mix[split:], [(alphas[l], tables[l - 1][split:]) for l in range(1, k + 1)])
+                ops.apply(user_t, mix, out, a=1.0)
+                wait(pending[k])
+                ops.lincomb(out[split:], [(alphas[l], tables[l][split:]) for l in range(0, k + 1)])
                 # + alpha_0 g on the seed users (each such row is owned by one lane group: read, add, write)
-                segment_sum(rows_s, torch.where(is_user, rows_s, none), vals_s, out, scale=alphas[0], accumulate=True)
-    return add_extra(out)
+                ops.segment_sum(rows_s, torch.where(is_user, rows_s, none), vals_s, out, scale=alphas[0], accumulate=True)
+    return finish(out)
 
 
 class RegHook:
@@ -519,8 +620,23 @@ def regularization_through(hook: RegHook, size: int, users: Tensor, pos: Tensor,
     """The regulariser of src/utils_v2.py:193-211 on ``hook.weight``, its gradient routed into the scoring node."""
     w = hook.weight.detach()
     value = (1 / 2) * (w[users].norm().pow(2) + w[pos].norm().pow(2) + w[neg].norm().pow(2)) / size * decay
-    hook.terms.append((torch.cat([users.reshape(-1), pos.reshape(-1), neg.reshape(-1)]), float(decay) / float(size)))
+    # upstream's gathers take CPU or int32 index tensors and negative (wrapping) ids on a CUDA table; the scoring node's
+    # backward hands these rows to lgc_segment_sum as raw int64 device pointers, so they are normalised here
+    rows = torch.cat([regularizer_rows(t, w) for t in (users, pos, neg)])
+    hook.terms.append((rows, float(decay) / float(size)))
     return _RegThroughHook.apply(hook.token, value)
+
+
+def routable_index(t) -> bool:
+    """An index argument the routed regulariser can take: an integer (not bool) tensor -- anything else upstream's
+    ``init_embed[idx]`` accepts (masks, lists, slices) goes through upstream's expression on plain torch ops."""
+    return torch.is_tensor(t) and t.dtype in (torch.int64, torch.int32, torch.int16, torch.int8, torch.uint8)
+
+
+def regularizer_rows(t: Tensor, w: Tensor) -> Tensor:
+    """Row ids of ``w[t]`` as a flat int64 vector on ``w``'s device, negative ids wrapped like torch's indexing."""
+    r = t.reshape(-1).to(device=w.device, dtype=torch.int64)
+    return torch.where(r < 0, r + w.size(0), r)
 
 
 def scores_from_table(w: Tensor, graph: PropGraph, alphas: Sequence[float], edge_label_index: Tensor,

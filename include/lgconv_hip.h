@@ -333,7 +333,9 @@ int lgc_lincomb(float *y, int64_t y_stride, const float *const *src, const int64
  *                 w <- w - step_size * m / (sqrt(v) / bias_correction2_sqrt + eps)
  * with step_size = lr / (1 - beta1^t) and bias_correction2_sqrt = sqrt(1 - beta2^t) computed by the host (t = step
  * count), and (1 - beta1), (1 - beta2) handed over as the host rounds them from double, like torch's own scalars
- * (1.0f - 0.999f is 4.7e-5 away from 0.001f).  All four pointers 16-byte aligned, n elements each.
+ * (1.0f - 0.999f is 4.7e-5 away from 0.001f).  n elements each; the four pointers dword-aligned and at the SAME offset
+ * inside a 16-byte line (LGC_E_ALIGN otherwise) -- 16-byte aligned tables, or the same row range of same-shaped tables:
+ * a rank of a partitioned run updates only the rows it owns (its users + the item block), two calls per step.
  * ------------------------------------------------------------------------------------- */
 int lgc_adam_step(float *w, const float *g, float *m, float *v, int64_t n, float one_minus_beta1, float beta2,
                   float one_minus_beta2, float eps, float step_size, float bias_correction2_sqrt, void *stream);

@@ -43,7 +43,7 @@ class CpuOps:
     def restrict(self, op, row_begin, row_end, short_max=None):
         return CpuOp(op.rowptr, op.cols, op.vals, row_begin, row_end)
 
-    def apply(self, op, x, out, a, r, b):
+    def apply(self, op, x, out, a=1.0, r=None, b=0.0):
         lo, hi = op.row_begin, op.row_end
         s, e = int(op.rowptr[lo]), int(op.rowptr[hi])
         rows = torch.repeat_interleave(torch.arange(lo, hi), op.rowptr[lo + 1:hi + 1] - op.rowptr[lo:hi]) - lo
@@ -52,3 +52,66 @@ class CpuOps:
         if r is not None:
             res = res + b * r[lo:hi]
         out[lo:hi] = res
+
+    # -- the rest of propagate.DeviceOps, in plain torch (same contracts, see include/lgconv_hip.h) --------------
+    def _rows_of(self, op, lo, hi):
+        s, e = int(op.rowptr[lo]), int(op.rowptr[hi])
+        rows = torch.repeat_interleave(torch.arange(lo, hi), op.rowptr[lo + 1:hi + 1] - op.rowptr[lo:hi])
+        return rows, op.cols[s:e], op.vals[s:e]
+
+    def apply_rows(self, op, rows, x, out, a=1.0, r=None, b=0.0):
+        """lgc_spmm_rows: the listed rows only (ids outside the operator's range skipped), the others untouched."""
+        for row in torch.unique(rows).tolist():
+            if not op.row_begin <= row < op.row_end:
+                continue
+            s, e = int(op.rowptr[row]), int(op.rowptr[row + 1])
+            acc = (op.vals[s:e].view(-1, 1) * x[op.cols[s:e]]).sum(0) if e > s else torch.zeros(x.size(1))
+            out[row] = a * acc + (b * r[row] if r is not None else 0.0)
+
+    def lincomb(self, y, terms):
+        acc = terms[0][1] * terms[0][0]
+        for c, t in terms[1:]:
+            acc = acc + t * c
+        y.copy_(acc)
+
+    def segment_sum(self, key_sorted, dest, vals, out, scale=1.0, accumulate=False):
+        """lgc_segment_sum: for every run head t with 0 <= dest[t] < rows: out[dest[t]] (+)= scale * sum of the run."""
+        m = key_sorted.numel()
+        if m == 0:
+            return
+        head = torch.ones(m, dtype=torch.bool)
+        head[1:] = key_sorted[1:] != key_sorted[:-1]
+        run = torch.cumsum(head.long(), 0) - 1
+        sums = torch.zeros(int(run[-1]) + 1, vals.size(1)).index_add_(0, run, vals)
+        d = dest[head]
+        ok = (d >= 0) & (d < out.size(0))
+        if accumulate:
+            out[d[ok]] = out[d[ok]] + scale * sums[ok]
+        else:
+            out[d[ok]] = scale * sums[ok]
+
+    def seed_pull(self, op, flag, slot, seed_vals, out, mark):
+        """lgc_seed_pull: rows of ``op``; an entry counts if its column carries a flag and then reads seed_vals[slot[col]]."""
+        lo, hi = op.row_begin, op.row_end
+        rows, cols, vals = self._rows_of(op, lo, hi)
+        on = flag[cols] != 0
+        acc = torch.zeros(hi - lo, seed_vals.size(1))
+        if bool(on.any()):
+            acc.index_add_(0, rows[on] - lo, vals[on].view(-1, 1) * seed_vals[slot[cols[on]].long()])
+        if mark is not None:                       # unmarked rows are zeros unread: they must not have had a flagged column
+            touched = torch.zeros(hi - lo, dtype=torch.bool)
+            touched[(rows[on] - lo)] = True
+            assert not bool((touched & (mark[lo:hi] == 0)).any()), "a row with a seed among its columns was not marked"
+        out[lo:hi] = acc
+
+    def seed_mark(self, op, rows_sorted, mark, value):
+        for row in torch.unique(rows_sorted).tolist():
+            if op.row_begin <= row < op.row_end:
+                c = op.cols[int(op.rowptr[row]):int(op.rowptr[row + 1])]
+                mark[c[c < mark.numel()]] = value
+
+    def pair_scores(self, emb, idx0, idx1):
+        return (emb[idx0] * emb[idx1]).sum(-1)
+
+    def scratch_table(self, like):
+        return torch.empty_like(like)

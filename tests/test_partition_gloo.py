@@ -81,7 +81,7 @@ def test_partitioned_propagate_matches_single_process_oracle(world, layers, dim,
         assert r["items_identical"]
 
 
-def _train_worker(rank, world, port, q):
+def _train_worker(rank, world, port, seeded, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     torch.set_num_threads(2)
@@ -110,8 +110,10 @@ def _train_worker(rank, world, port, q):
         # partitioned
         pp = PartitionedPropagator(ei, ew, g.n_users, g.n_items, rank, world, ops=CpuOps())
         w = w0.clone().requires_grad_(True)
+        from gnn_ecommerce_amd import propagate
+        propagate.SEED_ROWS_FACTOR = 0 if seeded else 10 ** 9
         local, gbpr, greg = partitioned_bpr_loss(pp, w, alpha.tolist(), users, pos, neg, decay,
-                                                 pair_scores=oracle.pair_scores)
+                                                 pair_scores=None if seeded else oracle.pair_scores)
         local.backward()
         lo, hi = pp.ranges[rank]
 
@@ -130,14 +132,15 @@ def _train_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("seeded", [True, False], ids=["seeded_node", "dense_backward"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_partitioned_training_step_matches_single_process_gradients(world):
+def test_partitioned_training_step_matches_single_process_gradients(world, seeded):
     """Row (e) of the hot-path contract end to end: forward, pair routing to the user's owner, BPR + regulariser,
     backward on A^T with the item-gradient all-reduce -- against the oracle's autograd on one process."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, seeded, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = dict(q.get(timeout=180) for _ in range(world))

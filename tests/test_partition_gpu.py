@@ -87,6 +87,13 @@ def test_two_ranks_one_gpu_match_single_gpu(device):
         assert 0.45 <= r["share"] <= 0.55
 
 
+def _uses_node(fn, name, depth=6):
+    """Whether an autograd graph contains a node whose class name holds ``name`` (searched a few levels deep)."""
+    if fn is None or depth == 0:
+        return False
+    return name in type(fn).__name__ or any(_uses_node(nxt, name, depth - 1) for nxt, _ in fn.next_functions)
+
+
 def _train_worker(rank, world, port, q, backend="gloo"):
     dev = _init(rank, world, port, backend)
     try:
@@ -111,22 +118,42 @@ def _train_worker(rank, world, port, q, backend="gloo"):
         w = model.embedding.weight
         reg = 0.5 * (w[users].norm().pow(2) + w[pos].norm().pow(2) + w[neg].norm().pow(2)) / batch * decay
         (bpr + reg).backward()
-        ref_grad = w.grad
+        ref_grad = w.grad.clone()
+        from gnn_ecommerce_amd.optim import Adam as HipAdam
+        HipAdam([w], lr=0.005).step()                       # the single-GPU step's dense Adam
+        ref_w = w.detach()
         # partitioned, real HipOps
+        from gnn_ecommerce_amd import partition
         pp = PartitionedPropagator(ei, ew, g.n_users, g.n_items, rank, world)
-        wp = w0.clone().requires_grad_(True)
-        local, gbpr, greg = partitioned_bpr_loss(pp, wp, [0.25] * 4, users, pos, neg, decay)
-        local.backward()
-        torch.cuda.synchronize()
         lo, hi = pp.ranges[rank]
 
         def rel(a, b):
             return ((a.double() - b.double()).norm() / b.double().norm()).item()
 
-        q.put((rank, {"bpr": abs(gbpr.item() - bpr.item()) / abs(bpr.item()),
-                      "reg": abs(greg.item() - reg.item()) / abs(reg.item()),
-                      "own": rel(wp.grad[lo:hi], ref_grad[lo:hi]), "items": rel(wp.grad[g.n_users:], ref_grad[g.n_users:]),
-                      "world": dist.get_world_size(), "backend": dist.get_backend()}))
+        res = {"world": dist.get_world_size(), "backend": dist.get_backend()}
+        for seeded in (True, False):
+            partition.SEEDED_STEP = seeded
+            wp = w0.clone().requires_grad_(True)
+            local, gbpr, greg = partitioned_bpr_loss(pp, wp, [0.25] * 4, users, pos, neg, decay, zero_foreign_rows=not seeded)
+            res[("seeded_" if seeded else "") + "node"] = _uses_node(local.grad_fn, "PartitionedScores")
+            local.backward()
+            torch.cuda.synchronize()
+            tag = "seeded_" if seeded else ""
+            res.update({tag + "bpr": abs(gbpr.item() - bpr.item()) / abs(bpr.item()),
+                        tag + "reg": abs(greg.item() - reg.item()) / abs(reg.item()),
+                        tag + "own": rel(wp.grad[lo:hi], ref_grad[lo:hi]),
+                        tag + "items": rel(wp.grad[g.n_users:], ref_grad[g.n_users:])})
+            if seeded:
+                # sharded Adam: only the rows this rank owns; they must equal the single-GPU dense step's rows, and the
+                # rows other ranks own must not have been touched
+                HipAdam([wp], lr=0.005, row_ranges=pp.owned_row_ranges()).step()
+                torch.cuda.synchronize()
+                res["adam_own"] = rel(wp.detach()[lo:hi] - w0[lo:hi], ref_w[lo:hi] - w0[lo:hi])
+                res["adam_items"] = rel(wp.detach()[g.n_users:] - w0[g.n_users:], ref_w[g.n_users:] - w0[g.n_users:])
+                foreign = torch.ones(g.n_users, dtype=torch.bool, device=dev)
+                foreign[lo:hi] = False
+                res["adam_foreign_untouched"] = bool(torch.equal(wp.detach()[:g.n_users][foreign], w0[:g.n_users][foreign]))
+        q.put((rank, res))
     finally:
         dist.destroy_process_group()
 
@@ -135,6 +162,9 @@ def test_two_ranks_training_step_matches_single_gpu(device):
     results = run_ranks(_train_worker, 2)
     for rank, r in results.items():
         assert r["bpr"] <= 1e-5 and r["reg"] <= 1e-5 and r["own"] <= 1e-5 and r["items"] <= 1e-5, (rank, r)
+        assert r["seeded_bpr"] <= 1e-5 and r["seeded_reg"] <= 1e-5 and r["seeded_own"] <= 1e-5 and r["seeded_items"] <= 1e-5, (rank, r)
+        assert r["seeded_node"] and not r["node"], (rank, r)
+        assert r["adam_own"] <= 1e-5 and r["adam_items"] <= 1e-5 and r["adam_foreign_untouched"], (rank, r)
 
 
 def test_exchange_hook_of_the_c_abi_drives_a_partitioned_hop(device):

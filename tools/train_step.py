@@ -23,10 +23,44 @@ ap.add_argument("--cpu-reference", type=int, default=0, metavar="THREADS",
                 help="also time the same step on the host with THREADS threads through the oracle's restatement of "
                      "the reference route (comparison only: BASELINE.json configs[4] quotes steps/s against it); "
                      "one warm-up step, one timed step")
+ap.add_argument("--world", type=int, default=1, help="> 1: the rank-local step of a WORLD-way partition on this one GPU, "
+                "every collective stubbed out (partition.partitioned_bpr_loss: seeded node, optim.Adam over the rows the "
+                "rank owns) -- local work only, what the exchange adds can only be measured on a multi-GPU node")
+ap.add_argument("--rank", type=int, default=0)
+ap.add_argument("--dense-partition", action="store_true", help="with --world: the dense partitioned backward (round 3)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 g = synth.make_bipartite(**synth.CONFIG_COSMETICS, seed=0)
 ei, ew = g.coo(dev)
+if args.world > 1:
+    import torch.distributed as dist
+    from gnn_ecommerce_amd import partition
+    from gnn_ecommerce_amd.optim import Adam as HipAdam
+    dist.all_reduce = lambda *a, **k: None                    # measurement stub: local work only
+    partition.SEEDED_STEP = not args.dense_partition
+    pp = partition.PartitionedPropagator(ei, ew, g.n_users, g.n_items, args.rank, args.world)
+    w = torch.nn.Parameter(synth.xavier_table(g.num_nodes, args.dim, 0, dev))
+    alphas = [1.0 / (args.layers + 1)] * (args.layers + 1)
+    popt = (HipAdam([w], 0.005, row_ranges=pp.owned_row_ranges()) if args.adam == "hip"
+            else torch.optim.Adam([w], 0.005, fused=(args.adam == "fused")))
+    pgen = torch.Generator().manual_seed(0)
+    def pstep():
+        popt.zero_grad()
+        u = torch.randint(0, g.n_users, (args.batch,), generator=pgen).to(dev)
+        p = (torch.randint(0, g.n_items, (args.batch,), generator=pgen) + g.n_users).to(dev)
+        n = (torch.randint(0, g.n_items, (args.batch,), generator=pgen) + g.n_users).to(dev)
+        local, gbpr, greg = partition.partitioned_bpr_loss(pp, w, alphas, u, p, n, 1e-4, zero_foreign_rows=args.adam != "hip")
+        local.backward()
+        popt.step()
+        return gbpr.item(), greg.item()                       # the host syncs of train_lightgcn.py:149-151
+    for _ in range(3): vals = pstep()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(args.steps): vals = pstep()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / args.steps
+    print(json.dumps({"metric": "rank-local training step, collectives stubbed (B=%d)" % args.batch, "world": args.world,
+                      "rank": args.rank, "users": [pp.u0, pp.u1], "ms_per_step": dt * 1e3, "dim": args.dim, "layers": args.layers,
+                      "adam": args.adam, "seeded": partition.SEEDED_STEP, "bpr_local_sum": vals[0]}))
+    sys.exit(0)
 model = lg.LightGCN(g.num_nodes, args.dim, args.layers).to(dev)
 if args.adam == "hip":
     from gnn_ecommerce_amd.optim import Adam as HipAdam
