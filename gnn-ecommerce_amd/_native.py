@@ -17,7 +17,7 @@ import torch
 LIB_NAME = "liblgconv_hip.so"
 # LGCN_LIB_PATH selects another build of the SAME library (A/B kernel experiments); never a fallback.
 LIB_PATH = os.environ.get("LGCN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", LIB_NAME)
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 # status bits (include/lgconv_hip.h)
 ST_INDEX_OOB = 1
@@ -89,8 +89,15 @@ SIGNATURES = {
                           c_int32, c_void_p]),
     "lgc_hop_exchange": (c_int, [POINTER(OperatorC), POINTER(OperatorC), c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
                                  c_int64, c_float, c_float, c_int32, c_int32, c_int32, c_int32, EXCHANGE_FN, c_void_p, c_void_p]),
-    "lgc_segment_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_int64, c_int64, c_int32, c_int32,
-                                c_void_p]),
+    "lgc_segment_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_int64, c_int64, c_int32,
+                                c_int32, c_void_p]),
+    "lgc_pair_dot_rows": (c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p]),
+    "lgc_bpr_loss": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "lgc_pair_seed_vals": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
+    "lgc_seed_prepare": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p]),
+    "lgc_seed_flags": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int32, c_void_p]),
     "lgc_seed_pull": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int32, c_void_p]),
     "lgc_seed_mark": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p]),
@@ -161,6 +168,7 @@ def require_device(t: torch.Tensor, name: str) -> None:
 
 
 MAX_TERMS = 8
+SEED_MAX = 8192        # LGC_SEED_MAX: ids one lgc_seed_prepare launch sorts
 
 
 def lincomb(y: torch.Tensor, terms) -> torch.Tensor:

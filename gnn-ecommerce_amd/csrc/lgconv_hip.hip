@@ -1343,7 +1343,8 @@ __global__ __launch_bounds__(kBlock) void k_sweep_combine(SpmmArgs p, const lgc_
 // owned by one lane group: no atomics, the same bits on every run -- the gradient of a scoring step has a few thousand
 // non-zero rows (src/lightgcn.py:123-125 scores 2B pairs), repeated nodes are summed here instead of by float atomics.
 __global__ __launch_bounds__(kBlock) void k_segment_sum(const int64_t *__restrict__ key, const int64_t *__restrict__ dest,
-                                                       const float *__restrict__ vals, int64_t n, float scale,
+                                                       const float *__restrict__ vals, const int32_t *__restrict__ vals_index,
+                                                       int64_t n, float scale,
                                                        float *__restrict__ y, int64_t y_stride, int64_t y_rows, int32_t dim,
                                                        int32_t accumulate) {
     const int lane = threadIdx.x & (kWave - 1);
@@ -1357,9 +1358,11 @@ __global__ __launch_bounds__(kBlock) void k_segment_sum(const int64_t *__restric
     if (d < 0 || d >= y_rows) return;
     const int c0 = l * 4;
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int64_t u = t; u < n && key[u] == k; ++u)
+    for (int64_t u = t; u < n && key[u] == k; ++u) {
+        const int64_t v = vals_index ? (int64_t)vals_index[u] : u;   // the sorted position's row of an UNSORTED value table
         for (int i = 0; i < 4; ++i)
-            if (c0 + i < dim) acc[i] = __fadd_rn(acc[i], vals[u * dim + c0 + i]);
+            if (c0 + i < dim) acc[i] = __fadd_rn(acc[i], vals[v * dim + c0 + i]);
+    }
     float *out = y + d * y_stride + c0;
     for (int i = 0; i < 4; ++i)
         if (c0 + i < dim) out[i] = __fadd_rn(accumulate ? out[i] : 0.0f, __fmul_rn(scale, acc[i]));
@@ -1380,6 +1383,150 @@ __global__ void k_seed_mark(const int32_t *__restrict__ rowptr, const lgc_entry 
         const int32_t c = entries[k].col;
         if (c >= 0 && c < mark_len) mark[c] = value;
     }
+}
+
+// ----------------------------------------------------------------------------------------
+// Seed preparation of the sparse backward pass (lgc_seed_prepare): ONE workgroup sorts up to kSeedMax row ids and
+// derives everything the segment sums and the seeded pull need -- what the host code did with ~25 small launches
+// (sort, gathers, compares, index_puts) per training step.
+// ----------------------------------------------------------------------------------------
+constexpr int kSeedMax = 8192;
+constexpr int kSeedBlock = 1024;
+
+__global__ __launch_bounds__(kSeedBlock) void k_seed_prepare(const int64_t *__restrict__ rows, int32_t m, int64_t split,
+                                                            int64_t n_nodes, int64_t *__restrict__ rows_sorted,
+                                                            int32_t *__restrict__ perm, int64_t *__restrict__ dest_item,
+                                                            int64_t *__restrict__ dest_slot, int64_t *__restrict__ dest_user,
+                                                            uint8_t *__restrict__ col_flag, int32_t *__restrict__ col_slot) {
+    __shared__ unsigned long long key[kSeedMax];
+    int n2 = 1;
+    while (n2 < m) n2 <<= 1;
+    // composite key: (row + 1) << 13 | position -- ascending order = stable sort by row; ids outside the table count
+    // as "no row" (-1) and sort to the front; padding sorts to the back
+    for (int i = threadIdx.x; i < n2; i += kSeedBlock) {
+        unsigned long long k = ~0ull;
+        if (i < m) {
+            int64_t r = rows[i];
+            if (r < 0 || r >= n_nodes) r = -1;
+            k = ((unsigned long long)(r + 1) << 13) | (unsigned)i;
+        }
+        key[i] = k;
+    }
+    __syncthreads();
+    for (int size = 2; size <= n2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < (n2 >> 1); t += kSeedBlock) {
+                const int lo = ((t / stride) * stride * 2) + (t % stride), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const unsigned long long a = key[lo], b = key[hi];
+                if ((a > b) == up) { key[lo] = b; key[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int t = threadIdx.x; t < m; t += kSeedBlock) {
+        const unsigned long long k = key[t];
+        const int64_t row = (int64_t)(k >> 13) - 1;
+        const bool head = t == 0 || (int64_t)(key[t - 1] >> 13) - 1 != row;
+        const bool user = row >= 0 && row < split, item = row >= split;
+        rows_sorted[t] = row;
+        perm[t] = (int32_t)(k & 0x1FFF);
+        dest_item[t] = (head && item) ? row : -1;
+        dest_slot[t] = (head && user) ? t : -1;
+        dest_user[t] = (head && user) ? row : -1;
+        if (head && user && col_flag) {
+            col_flag[row] = 1;
+            col_slot[row] = t;
+        }
+    }
+}
+
+// flag[row] = value for the user rows (0 <= row < split) of a sorted row list: takes the flags of a step's seeds back
+__global__ void k_seed_flags(const int64_t *__restrict__ rows_sorted, int64_t m, int64_t split, uint8_t *__restrict__ flag,
+                             uint8_t value) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    const int64_t row = rows_sorted[t];
+    if (row >= 0 && row < split) flag[row] = value;
+}
+
+// Pair scoring that keeps what the backward pass needs (lgc_pair_dot_rows): scores as k_pair_dot, plus the two gathered
+// rows of every pair and a validity byte -- instead of four compares, three ands, two clamps and two row gathers on the
+// host side.  An out-of-range pair scores NaN, keeps zero rows, ok = 0, and raises the status bit.
+__global__ __launch_bounds__(kBlock) void k_pair_dot_rows(const float *__restrict__ emb, int64_t stride, int32_t dim,
+                                                         int64_t n_nodes, const int64_t *__restrict__ idx0,
+                                                         const int64_t *__restrict__ idx1, int64_t n_pairs,
+                                                         float *__restrict__ scores, float *__restrict__ rows0,
+                                                         float *__restrict__ rows1, uint8_t *__restrict__ ok,
+                                                         int32_t *__restrict__ status) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t m = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x / kWave);
+    if (m >= n_pairs) return;
+    const int64_t a = idx0[m], b = idx1[m];
+    const bool valid = a >= 0 && a < n_nodes && b >= 0 && b < n_nodes;   // wave-uniform
+    if (!valid && lane == 0) {
+        atomicOr(status, LGC_ST_INDEX_OOB);
+        scores[m] = NAN;
+    }
+    if (lane == 0 && ok) ok[m] = valid ? 1 : 0;
+    const float *pa = emb + a * stride, *pb = emb + b * stride;
+    float s = 0.0f;
+    for (int c = lane; c < dim; c += kWave) {
+        const float va = valid ? pa[c] : 0.0f, vb = valid ? pb[c] : 0.0f;
+        s += va * vb;
+        if (rows0) rows0[m * dim + c] = va;
+        if (rows1) rows1[m * dim + c] = vb;
+    }
+    if (!valid) return;
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) scores[m] = s;
+}
+
+// The seed of the backward pass from the gradient of the scores (lgc_pair_seed_vals):
+//   vals[m]           = g[m] * rows1[m]      d score_m / d out[idx0[m]] = out[idx1[m]]
+//   vals[n_pairs + m] = g[m] * rows0[m]      d score_m / d out[idx1[m]] = out[idx0[m]]
+// with g[m] = mask[m] ? grad_scores[m] * (*grad_scale) : 0.  grad_scale: an optional DEVICE scalar (the upstream
+// gradient of a loss this node computed itself), so that no host sync is needed to read it.
+__global__ __launch_bounds__(kBlock) void k_pair_seed_vals(const float *__restrict__ grad_scores, const uint8_t *__restrict__ mask,
+                                                          const float *__restrict__ grad_scale, const float *__restrict__ rows0,
+                                                          const float *__restrict__ rows1, int64_t n_pairs, int32_t dim,
+                                                          float *__restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs * dim) return;
+    const int64_t m = i / dim;
+    float g = (mask == nullptr || mask[m]) ? grad_scores[m] : 0.0f;
+    if (grad_scale) g = __fmul_rn(g, *grad_scale);
+    vals[i] = __fmul_rn(g, rows1[i]);
+    vals[n_pairs * dim + i] = __fmul_rn(g, rows0[i]);
+}
+
+// BPR loss of one batch of triples and its gradient with respect to the scores (lgc_bpr_loss): what
+// `recommendation_loss(out[:B], out[B:], 0) * B` of src/train_lightgcn.py:141 (src/lightgcn.py:262-286 with lambda_reg = 0)
+// and its autograd compute with ~15 launches:  loss = -sum_{t: mask[t]} log sigmoid(s[t] - s[B + t]) / size,
+// grad[t] = -sigmoid(-(s[t] - s[B + t])) / size, grad[B + t] = -grad[t] (0 where the mask is off).  One workgroup, a fixed
+// reduction tree: the same bits on every run.  logsigmoid(d) = min(d, 0) - log1p(exp(-|d|)), torch's formula.
+__global__ __launch_bounds__(kSeedBlock) void k_bpr_loss(const float *__restrict__ scores, const uint8_t *__restrict__ mask,
+                                                        int64_t n_triples, float inv_size, float *__restrict__ loss,
+                                                        float *__restrict__ grad) {
+    __shared__ float part[kSeedBlock];
+    float acc = 0.0f;
+    for (int64_t t = threadIdx.x; t < n_triples; t += kSeedBlock) {
+        const bool on = mask == nullptr || mask[t] != 0;
+        const float d = on ? scores[t] - scores[n_triples + t] : 0.0f;
+        const float ls = fminf(d, 0.0f) - log1pf(expf(-fabsf(d)));
+        const float sg = 1.0f / (1.0f + expf(d));                  // sigmoid(-d)
+        if (on) acc += ls;
+        grad[t] = on ? -sg * inv_size : 0.0f;
+        grad[n_triples + t] = on ? sg * inv_size : 0.0f;
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = kSeedBlock / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = -part[0] * inv_size;
 }
 
 struct LincombArgs {
@@ -2532,14 +2679,64 @@ int lgc_hop_exchange(const lgc_operator *item_op, const lgc_operator *user_op, i
     return lgc_apply(user_op, table_rows, x, x_stride, y, y_stride, r, r_stride, a, b, dim, stream);
 }
 
-int lgc_segment_sum(const int64_t *key_sorted, const int64_t *dest, const float *vals, int64_t n, float scale, float *y,
-                    int64_t y_stride, int64_t y_rows, int32_t dim, int32_t accumulate, void *stream_) {
+int lgc_segment_sum(const int64_t *key_sorted, const int64_t *dest, const float *vals, const int32_t *vals_index, int64_t n,
+                    float scale, float *y, int64_t y_stride, int64_t y_rows, int32_t dim, int32_t accumulate, void *stream_) {
     if (!y || n < 0 || y_rows < 0 || dim < 1 || dim > 256 || y_stride < dim) return LGC_E_INVAL;
     if (n == 0) return 0;
     if (!key_sorted || !dest || !vals) return LGC_E_INVAL;
     const int groups = kWave / ((dim + 3) / 4);
     hipLaunchKernelGGL(k_segment_sum, dim3(ceil_div(n, (int64_t)(kBlock / kWave) * groups)), dim3(kBlock), 0, as_stream(stream_),
-                       key_sorted, dest, vals, n, scale, y, y_stride, y_rows, dim, accumulate);
+                       key_sorted, dest, vals, vals_index, n, scale, y, y_stride, y_rows, dim, accumulate);
+    return (int)hipGetLastError();
+}
+
+int lgc_seed_prepare(const int64_t *rows, int64_t m, int64_t split, int64_t n_nodes, int64_t *rows_sorted, int32_t *perm,
+                     int64_t *dest_item, int64_t *dest_slot, int64_t *dest_user, uint8_t *col_flag, int32_t *col_slot,
+                     void *stream_) {
+    if (m < 0 || m > LGC_SEED_MAX) return LGC_E_RANGE;
+    if (split < 0 || n_nodes < split || (col_flag != nullptr) != (col_slot != nullptr)) return LGC_E_INVAL;
+    if (m == 0) return 0;
+    if (!rows || !rows_sorted || !perm || !dest_item || !dest_slot || !dest_user) return LGC_E_INVAL;
+    hipLaunchKernelGGL(k_seed_prepare, dim3(1), dim3(kSeedBlock), 0, as_stream(stream_), rows, (int32_t)m, split, n_nodes,
+                       rows_sorted, perm, dest_item, dest_slot, dest_user, col_flag, col_slot);
+    return (int)hipGetLastError();
+}
+
+int lgc_seed_flags(const int64_t *rows_sorted, int64_t m, int64_t split, uint8_t *col_flag, int32_t value, void *stream_) {
+    if (m < 0 || split < 0 || value < 0 || value > 255) return LGC_E_INVAL;
+    if (m == 0) return 0;
+    if (!rows_sorted || !col_flag) return LGC_E_INVAL;
+    hipLaunchKernelGGL(k_seed_flags, dim3(ceil_div(m, kBlock)), dim3(kBlock), 0, as_stream(stream_), rows_sorted, m, split,
+                       col_flag, (uint8_t)value);
+    return (int)hipGetLastError();
+}
+
+int lgc_pair_dot_rows(const float *emb, int64_t stride, int32_t dim, int64_t n_nodes, const int64_t *idx0, const int64_t *idx1,
+                      int64_t n_pairs, float *scores, float *rows0, float *rows1, uint8_t *ok, int32_t *status, void *stream_) {
+    if (!emb || !status || dim < 1 || stride < dim || n_nodes < 0 || n_pairs < 0) return LGC_E_INVAL;
+    if (n_pairs == 0) return 0;
+    if (!idx0 || !idx1 || !scores) return LGC_E_INVAL;
+    hipLaunchKernelGGL(k_pair_dot_rows, dim3(ceil_div(n_pairs, kBlock / kWave)), dim3(kBlock), 0, as_stream(stream_), emb, stride,
+                       dim, n_nodes, idx0, idx1, n_pairs, scores, rows0, rows1, ok, status);
+    return (int)hipGetLastError();
+}
+
+int lgc_pair_seed_vals(const float *grad_scores, const uint8_t *mask, const float *grad_scale, const float *rows0,
+                       const float *rows1, int64_t n_pairs, int32_t dim, float *vals, void *stream_) {
+    if (n_pairs < 0 || dim < 1) return LGC_E_INVAL;
+    if (n_pairs == 0) return 0;
+    if (!grad_scores || !rows0 || !rows1 || !vals) return LGC_E_INVAL;
+    hipLaunchKernelGGL(k_pair_seed_vals, dim3(ceil_div(n_pairs * dim, kBlock)), dim3(kBlock), 0, as_stream(stream_), grad_scores,
+                       mask, grad_scale, rows0, rows1, n_pairs, dim, vals);
+    return (int)hipGetLastError();
+}
+
+int lgc_bpr_loss(const float *scores, const uint8_t *mask, int64_t n_triples, int64_t size, float *loss, float *grad,
+                 void *stream_) {
+    if (!loss || n_triples < 0 || size <= 0) return LGC_E_INVAL;
+    if (n_triples > 0 && (!scores || !grad)) return LGC_E_INVAL;
+    hipLaunchKernelGGL(k_bpr_loss, dim3(1), dim3(kSeedBlock), 0, as_stream(stream_), scores, mask, n_triples,
+                       1.0f / (float)size, loss, grad);
     return (int)hipGetLastError();
 }
 

@@ -43,7 +43,8 @@ TILE_ORDER = os.environ.get("LGCN_TILE_ORDER", "cold")
 # Band sweep for the long rows of a bipartite half whose gathered table is far larger than the caches (the item
 # step): "auto" = when the half has at least SWEEP_MIN_ENTRIES entries, "1" = whenever the table qualifies, "0" = never.
 USE_SWEEP = os.environ.get("LGCN_SWEEP", "auto")
-SWEEP_MIN_ENTRIES = int(os.environ.get("LGCN_SWEEP_MIN_ENTRIES", "2000000"))
+SWEEP_MIN_ENTRIES = int(os.environ.get("LGCN_SWEEP_MIN_ENTRIES", "1000000"))
+SWEEP_ADAPTIVE_BANDS = os.environ.get("LGCN_SWEEP_ADAPTIVE_BANDS", "1") == "1"
 # 8 wavefronts per CU with 78 accumulators each beat 16 x 39 (44 % vs 20 % L2 hits on the item step: fewer, longer
 # lists keep the wavefronts of a band closer together); 160 KiB of LDS per CU either way.
 SWEEP_CFG = dict(n_bands=int(os.environ.get("LGCN_SWEEP_BANDS", "8")), waves_per_band_round=int(os.environ.get("LGCN_SWEEP_WAVES", "256")),
@@ -284,6 +285,7 @@ class Operator:
     plan: RowPlan
     tiled: bool = False                  # rows up to plan.short_max go through the tiled kernels
     sweep_cols: Optional[Tuple[int, int]] = None    # column range of a bipartite half that qualifies for the band sweep
+    sweep_bands: int = 0                            # bands of that sweep (0: the configured number)
     _sweep: Dict[int, SweepPlan] = field(default_factory=dict)     # by entries per step: 4 (61..64 columns), 2 (68..96)
     _tiles: Optional[List[TileClass]] = None
     _partials: Dict[int, Tensor] = field(default_factory=dict)
@@ -310,9 +312,16 @@ class Operator:
             # a piece (row x band) should hold ~10 entries or its LDS zero-fill / write-out / combine outweigh the
             # reuse it buys: measured on slices of the item half, 5.1 M entries (93 per row): 325 vs 346 us with the
             # sweep, 2.5 M (46 per row): 208 vs 193, 1.3 M: 134 vs 112
-            dense_enough = n_ent >= max(SWEEP_MIN_ENTRIES, 10 * SWEEP_CFG["n_bands"] * n_rows)
+            # Fewer bands for a thinner slice (a rank's item rows at world 4 / 8 hold 1/4, 1/8 of each row's entries): the
+            # most bands -- up to one per XCD -- that still leave ~10 entries per piece; a band then spans 8 / bands XCDs
+            # (block % bands) and the waves per band and round grow so that a round still fills the chip.
+            bands = SWEEP_CFG["n_bands"]
+            while SWEEP_ADAPTIVE_BANDS and bands > 2 and n_ent < 10 * bands * n_rows:
+                bands //= 2
+            dense_enough = n_ent >= max(SWEEP_MIN_ENTRIES, 10 * bands * n_rows)
             if long_rows and (USE_SWEEP == "1" or (dense_enough and n_cols >= 1 << 17)):
                 op.sweep_cols = (int(sweep_cols[0]), int(sweep_cols[1]))
+                op.sweep_bands = bands
         return op
 
     def sweep_plan(self, groups: int = 4) -> Optional[SweepPlan]:
@@ -323,8 +332,10 @@ class Operator:
         plan = self._sweep.get(groups)
         if plan is None:
             p = self.plan
-            plan = SweepPlan(self.rowptr, self.entries, p.row_begin, p.row_end, *self.sweep_cols,
-                             cfg=SWEEP_CFG_WIDE if groups == 2 else SWEEP_CFG)
+            cfg = dict(SWEEP_CFG_WIDE if groups == 2 else SWEEP_CFG)
+            if self.sweep_bands and self.sweep_bands != cfg["n_bands"]:
+                cfg.update(n_bands=self.sweep_bands, waves_per_band_round=cfg["waves_per_band_round"] * cfg["n_bands"] // self.sweep_bands)
+            plan = SweepPlan(self.rowptr, self.entries, p.row_begin, p.row_end, *self.sweep_cols, cfg=cfg)
             self._sweep[groups] = plan
         return plan
 

@@ -237,6 +237,8 @@ class PartitionedPropagator:
             if layer < k:
                 self.ops.apply(user_op, prev, cur, 1.0, None, 0.0)
             else:
+                # (the two weighted sums over the 14 MB item blocks, 17 us each, on a second stream beside the last item /
+                # user step: 119.7 vs 107.1 us per hop at world 8 -- the cross-stream events cost more than they hide)
                 self._lincomb(mix[nu:], [(alphas[l], tables[l - 1][nu:]) for l in range(1, k + 1)])
                 if final_rows is None:
                     self.ops.apply(user_op, mix, out, 1.0, x0, alphas[0])
@@ -332,55 +334,63 @@ def own_pairs(pp: PartitionedPropagator, edge_label_index: Tensor) -> Tensor:
 SEEDED_STEP = os.environ.get("LGCN_PARTITION_SEEDED", "1") == "1"
 
 
-class _PartitionedScores(torch.autograd.Function):
-    """Scores of ONE global batch on a rank of a partition, as one autograd node -- the partitioned form of
-    propagate._ScoresFromTable (src/lightgcn.py:121-125 behind src/train_lightgcn.py:138):
+class _PartitionedStep(torch.autograd.Function):
+    """The local part of the loss of ONE global batch (src/train_lightgcn.py:137-144: bpr * size + reg) on a rank of a
+    partition, as one autograd node -- the partitioned form of propagate._ScoresFromTable with the loss folded in:
 
-    forward   propagate on the partition, the last user step for the batch's own users only (lgc_spmm_rows), then
-              lgc_pair_dot for all 2B pairs with FIXED shapes: a triple whose user another rank owns is scored against
-              an own user row standing in for it (the id clamped into [u0, u1)) and masked out by the caller, so that no
-              step needs the host to know how many triples a rank owns (no sync, no dynamic shapes);
-    backward  the seed of the transposed propagation: user rows from this rank's own pairs; item rows from EVERY rank's
-              pairs -- d score / d out[item] = gs * out[user] is known to the user's owner only, so the [2B, D] table of
-              those products (zero rows for foreign pairs) is summed over the ranks: 0.5 MB instead of the 14 MB item
-              block of a dense gradient; then propagate.seeded_sum on the rank's local halves of A^T with the per-hop
-              item-block exchange.  The regulariser's rows (own users of the batch, all items of the batch) are added
-              by the same node.  Result: the gradient of the rows this rank owns; other ranks' user rows are left
-              unwritten unless ``zero_foreign``.
-    Second output: the zero-valued token a regulariser routes its gradient through (propagate.RegHook's mechanism)."""
+    forward   propagate on the partition, the last user step for the batch's users only (lgc_spmm_rows); lgc_pair_dot_rows
+              for all 2B pairs with FIXED shapes -- a triple whose user another rank owns is scored against an own user row
+              standing in for it (the id clamped into [u0, u1)) and masked out of the loss, so that no step needs the host
+              to know how many triples a rank owns (no sync, no dynamic shapes); lgc_bpr_loss (the BPR term over the own
+              triples and its gradient with respect to the scores, one launch); the regulariser of the rows this rank
+              accounts for: its own users of the batch, every item of the batch (item rows are replicated).
+    backward  the seed of the transposed propagation (lgc_pair_seed_vals): user rows from this rank's own pairs; item rows
+              from EVERY rank's pairs -- d score / d out[item] = g * out[user] is known to the user's owner only, so the
+              [2B, D] table of those products (zero rows for foreign pairs) is summed over the ranks: 0.5 MB instead of the
+              14 MB item block of a dense gradient; then propagate.seeded_sum on the rank's local halves of A^T with the
+              per-hop item-block exchange, the regulariser's rows added by the same node.  Result: the gradient of the rows
+              this rank owns; other ranks' user rows are left unwritten unless ``zero_foreign``.
+    Outputs: (local loss, local bpr, regulariser of own users, regulariser of the batch's items) -- the last three for
+    logging, not differentiable."""
 
     @staticmethod
     def forward(ctx, w: Tensor, pp: "PartitionedPropagator", alphas: tuple, users: Tensor, pos: Tensor, neg: Tensor,
-                reg_scale: float, zero_foreign: bool):
+                decay: float, zero_foreign: bool):
         ops = pp.ops
+        size = users.numel()
         mine = (users >= pp.u0) & (users < pp.u1)
-        uc = users.clamp(pp.u0, pp.u1 - 1)                       # foreign users: any own row stands in, masked out later
+        uc = users.clamp(pp.u0, pp.u1 - 1)                       # foreign users: any own row stands in, masked out below
         idx0, idx1 = torch.cat([uc, uc]), torch.cat([pos, neg])
         emb = pp.propagate_sum(w.detach(), alphas, final_rows=uc)
-        scores = ops.pair_scores(emb, idx0, idx1)
-        ctx.save_for_backward(emb[idx0], emb[idx1], idx0, idx1, torch.cat([mine, mine]), w)
-        ctx.pp, ctx.alphas, ctx.reg_scale, ctx.zero_foreign = pp, alphas, reg_scale, zero_foreign
+        scores, e0, e1, _ = ops.pair_scores_rows(emb, idx0, idx1)
+        mine_b = mine.to(torch.uint8)
+        bpr_local, gs = ops.bpr_loss(scores, mine_b, size)
+        park = torch.full_like(uc, -1)                           # rows other ranks own: "no row" for the seed
+        own_u = torch.where(mine, uc, park)
+        wr = w.detach()[torch.cat([uc, pos, neg])]               # the 3B layer-0 rows of src/utils_v2.py:193-211
+        sq = wr.pow(2).sum(1)
+        reg_users = (sq[:size] * mine.to(sq.dtype)).sum() * (0.5 * decay / size)
+        reg_items = sq[size:].sum() * (0.5 * decay / size)
+        ctx.save_for_backward(e0, e1, gs, torch.cat([mine_b, mine_b]), torch.cat([own_u, own_u, idx1]),
+                              torch.cat([own_u, idx1]), wr)
+        ctx.pp, ctx.alphas, ctx.reg_scale, ctx.zero_foreign = pp, alphas, float(decay) / float(size), zero_foreign
         ctx.set_materialize_grads(False)
-        return scores, torch.zeros((), dtype=torch.float32, device=w.device)
+        local = bpr_local + reg_users + reg_items
+        ctx.mark_non_differentiable(bpr_local, reg_users, reg_items)
+        return local, bpr_local, reg_users, reg_items
 
     @staticmethod
-    def backward(ctx, grad_scores: Optional[Tensor], grad_token: Optional[Tensor]):
-        e0, e1, idx0, idx1, mine2, w = ctx.saved_tensors
+    def backward(ctx, grad_local: Optional[Tensor], *unused):
+        e0, e1, gs, mine2, rows, reg_rows, wr = ctx.saved_tensors
         pp = ctx.pp
-        if grad_scores is None:
-            grad_scores = torch.zeros(idx0.numel(), dtype=torch.float32, device=e0.device)
-        gs = torch.where(mine2, grad_scores, torch.zeros_like(grad_scores)).unsqueeze(1)
-        item_vals = (gs * e0).contiguous()                       # d / d out[item of pair m]: non-zero on the user's owner only
-        if pp.world > 1:
-            dist.all_reduce(item_vals, op=dist.ReduceOp.SUM, group=pp.group)
-        rows = torch.cat([idx0, idx1])
-        vals = torch.cat([gs * e1, item_vals])
-        extra = []
-        if grad_token is not None and ctx.reg_scale != 0.0:
-            wd = w.detach()
-            b = idx0.numel() // 2                                # idx0 = [u | u], idx1 = [pos | neg]: each row once
-            own = mine2[:b].to(wd.dtype).unsqueeze(1)            # a user row's regulariser term belongs to its owner
-            extra = [(torch.cat([idx0[:b], idx1]), torch.cat([wd[idx0[:b]] * own, wd[idx1]]) * grad_token, ctx.reg_scale)]
+        if grad_local is None:
+            grad_local = torch.zeros((), dtype=torch.float32, device=e0.device)
+        grad_local = grad_local.to(torch.float32).contiguous()
+        vals = pp.ops.pair_seed_vals(gs, mine2, grad_local, e0, e1)     # [4B, D]: user rows | item rows
+        m2 = e0.size(0)
+        if pp.world > 1:                                                 # d / d out[item of pair m]: non-zero on the user's owner
+            dist.all_reduce(vals[m2:], op=dist.ReduceOp.SUM, group=pp.group)
+        extra = [(reg_rows, wr * grad_local, ctx.reg_scale)] if ctx.reg_scale != 0.0 else []
         zero = [(0, pp.u0), (pp.u1, pp.n_users)] if ctx.zero_foreign else None
         return pp.seeded_transpose_sum(rows, vals, ctx.alphas, extra, zero), None, None, None, None, None, None, None
 
@@ -395,7 +405,7 @@ def partitioned_bpr_loss(pp: PartitionedPropagator, weight: Tensor, alphas: Sequ
     regulariser's item terms are evaluated on every rank (replicated parameters), its user terms on the
     owner only.  Returns (local_loss, global_bpr, global_reg) -- the two globals detached, for logging.
 
-    With a batch far smaller than the table (the training case) the step is one seeded node (_PartitionedScores):
+    With a batch far smaller than the table (the training case) the step is one seeded node (_PartitionedStep):
     scored-rows-only last user step, seeded backward on the rank's halves of A^T, the regulariser's gradient inside the
     same node, no dense [N, D] gradient anywhere and no host sync.  ``zero_foreign_rows=False`` additionally leaves the
     user rows other ranks own unwritten in ``weight.grad`` (a caller that updates only ``pp.owned_row_ranges()``, like
@@ -409,16 +419,8 @@ def partitioned_bpr_loss(pp: PartitionedPropagator, weight: Tensor, alphas: Sequ
               and 2 * size * propagate.SEED_ROWS_FACTOR <= weight.size(0))
     if seeded:
         alphas = tuple(float(a) for a in alphas)
-        scores, token = _PartitionedScores.apply(weight, pp, alphas, users, pos, neg, float(decay) / float(size),
-                                                 zero_foreign_rows)
-        mine = (users >= pp.u0) & (users < pp.u1)
-        diff = torch.where(mine, scores[:size] - scores[size:], torch.zeros_like(scores[:size]))
-        bpr_local = -(torch.nn.functional.logsigmoid(diff) * mine.to(scores.dtype)).sum() / size
-        wd = weight.detach()
-        uc = users.clamp(pp.u0, pp.u1 - 1)
-        reg_users = 0.5 * (wd[uc] * mine.to(wd.dtype).unsqueeze(1)).norm().pow(2) / size * decay
-        reg_items = 0.5 * (wd[pos].norm().pow(2) + wd[neg].norm().pow(2)) / size * decay
-        local = bpr_local + propagate._RegThroughHook.apply(token, reg_users + reg_items)
+        local, bpr_local, reg_users, reg_items = _PartitionedStep.apply(weight, pp, alphas, users, pos, neg, float(decay),
+                                                                        zero_foreign_rows)
     else:
         if pair_scores is None:
             from .propagate import pair_dot as pair_scores

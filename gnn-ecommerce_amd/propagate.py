@@ -285,9 +285,11 @@ class _PairDot(torch.autograd.Function):
         return grad, None, None
 
 
-def segment_sum(key_sorted: Tensor, dest: Tensor, vals: Tensor, out: Tensor, scale: float = 1.0, accumulate: bool = False) -> None:
+def segment_sum(key_sorted: Tensor, dest: Tensor, vals: Tensor, out: Tensor, scale: float = 1.0, accumulate: bool = False,
+                vals_index: Optional[Tensor] = None) -> None:
     """out[dest[t]] (+)= scale * (sum of vals over the run of equal keys that starts at t), for every run head t with
-    dest[t] >= 0: lgc_segment_sum -- one lane group per destination row, fixed order, no atomics."""
+    dest[t] >= 0: lgc_segment_sum -- one lane group per destination row, fixed order, no atomics.  ``vals_index`` (int32):
+    the value row of sorted position t is vals[vals_index[t]] (the permutation of the sort; vals stays unsorted)."""
     lib = _native.load()
     _native.require_device(out, "segment_sum: out")
     if out.dtype != torch.float32 or out.dim() != 2 or out.stride(1) != 1:
@@ -302,8 +304,12 @@ def segment_sum(key_sorted: Tensor, dest: Tensor, vals: Tensor, out: Tensor, sca
             or vals.device != out.device):
         raise TypeError(f"segment_sum: vals must be a contiguous fp32 [{m}, {out.size(1)}] tensor on {out.device}, got "
                         f"{vals.dtype} {tuple(vals.shape)} on {vals.device}")
+    if vals_index is not None and (vals_index.dtype != torch.int32 or vals_index.shape != (m,) or not vals_index.is_contiguous()
+                                   or vals_index.device != out.device):
+        raise TypeError(f"segment_sum: vals_index must be a contiguous int32 vector of {m} entries on {out.device}")
     with torch.cuda.device(out.device):
-        code = lib.lgc_segment_sum(_native.ptr(key_sorted), _native.ptr(dest), _native.ptr(vals), key_sorted.numel(), float(scale),
+        code = lib.lgc_segment_sum(_native.ptr(key_sorted), _native.ptr(dest), _native.ptr(vals), _native.ptr(vals_index),
+                                   key_sorted.numel(), float(scale),
                                    _native.ptr(out), out.stride(0), out.size(0), out.size(1), int(accumulate),
                                    _native.stream_of(out.device))
     _native.check(code, "lgc_segment_sum")
@@ -402,6 +408,76 @@ class DeviceOps:
     def seed_pull(self, op: Operator, flag: Tensor, slot: Tensor, seed_vals: Tensor, out: Tensor, mark: Optional[Tensor]) -> None:
         _seed_pull(op, flag, slot, seed_vals, out, mark)
 
+    def seed_prepare(self, rows: Tensor, split: int, n: int, flag: Optional[Tensor] = None, slot: Optional[Tensor] = None):
+        """Sort the seed's row ids and derive the destination lists of its segment sums (lgc_seed_prepare, one launch):
+        (rows_sorted, perm int32, dest_item, dest_slot, dest_user) -- see include/lgconv_hip.h.  With ``flag`` / ``slot``:
+        the column map of the seeded pull is set for the user heads as well.  Seeds above LGC_SEED_MAX ids take the same
+        steps as torch ops."""
+        m = rows.numel()
+        dev = rows.device
+        if m > _native.SEED_MAX:
+            return seed_prepare_reference(rows, split, n, flag, slot)
+        rows = rows.contiguous()
+        i64 = dict(dtype=torch.int64, device=dev)
+        buf = torch.empty((4, max(m, 1)), **i64)
+        perm = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
+        lib = _native.load()
+        with torch.cuda.device(dev):
+            code = lib.lgc_seed_prepare(_native.ptr(rows), m, int(split), int(n), _native.ptr(buf[0]), _native.ptr(perm),
+                                        _native.ptr(buf[1]), _native.ptr(buf[2]), _native.ptr(buf[3]), _native.ptr(flag),
+                                        _native.ptr(slot), _native.stream_of(dev))
+        _native.check(code, "lgc_seed_prepare")
+        return buf[0, :m], perm[:m], buf[1, :m], buf[2, :m], buf[3, :m]
+
+    def seed_flags(self, rows_sorted: Tensor, split: int, flag: Tensor, value: int) -> None:
+        lib = _native.load()
+        with torch.cuda.device(flag.device):
+            code = lib.lgc_seed_flags(_native.ptr(rows_sorted), rows_sorted.numel(), int(split), _native.ptr(flag), int(value),
+                                      _native.stream_of(flag.device))
+        _native.check(code, "lgc_seed_flags")
+
+    def pair_scores_rows(self, emb: Tensor, idx0: Tensor, idx1: Tensor):
+        """(scores [M], rows0 [M, D], rows1 [M, D], ok uint8 [M]): lgc_pair_dot_rows -- the scores of src/lightgcn.py:123-125
+        and, in the same launch, the gathered rows and validity bytes its backward needs."""
+        lib = _native.load()
+        m, dim, dev = idx0.numel(), emb.size(1), emb.device
+        scores = torch.empty(m, dtype=torch.float32, device=dev)
+        rows = torch.empty((2, m, dim), dtype=torch.float32, device=dev)
+        ok = torch.empty(m, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            code = lib.lgc_pair_dot_rows(_native.ptr(emb), emb.stride(0), dim, emb.size(0), _native.ptr(idx0), _native.ptr(idx1), m,
+                                         _native.ptr(scores), _native.ptr(rows[0]), _native.ptr(rows[1]), _native.ptr(ok),
+                                         _native.ptr(_status(dev)), _native.stream_of(dev))
+        _native.check(code, "lgc_pair_dot_rows")
+        _snapshot_status(dev)
+        return scores, rows[0], rows[1], ok
+
+    def pair_seed_vals(self, grad_scores: Tensor, mask: Optional[Tensor], grad_scale: Optional[Tensor], rows0: Tensor,
+                       rows1: Tensor) -> Tensor:
+        """vals [2M, D]: vals[m] = g_m rows1[m], vals[M + m] = g_m rows0[m], g_m = mask[m] ? grad_scores[m] * grad_scale : 0
+        (lgc_pair_seed_vals; ``grad_scale`` a 0-dim device tensor or None)."""
+        lib = _native.load()
+        m, dim, dev = rows0.size(0), rows0.size(1), rows0.device
+        grad_scores = grad_scores.contiguous()
+        vals = torch.empty((2 * m, dim), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            code = lib.lgc_pair_seed_vals(_native.ptr(grad_scores), _native.ptr(mask), _native.ptr(grad_scale), _native.ptr(rows0),
+                                          _native.ptr(rows1), m, dim, _native.ptr(vals), _native.stream_of(dev))
+        _native.check(code, "lgc_pair_seed_vals")
+        return vals
+
+    def bpr_loss(self, scores: Tensor, mask: Optional[Tensor], size: int):
+        """(loss 0-dim, grad [2B]): lgc_bpr_loss on scores = [pos | neg]."""
+        lib = _native.load()
+        dev = scores.device
+        b = scores.numel() // 2
+        out = torch.empty(1 + 2 * b, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            code = lib.lgc_bpr_loss(_native.ptr(scores), _native.ptr(mask), b, int(size), _native.ptr(out), _native.ptr(out[1:]),
+                                    _native.stream_of(dev))
+        _native.check(code, "lgc_bpr_loss")
+        return out[0], out[1:]
+
     def seed_mark(self, op: Operator, rows_sorted: Tensor, mark: Tensor, value: int) -> None:
         _seed_mark(op, rows_sorted, mark, value)
 
@@ -419,6 +495,27 @@ class DeviceOps:
 
     def scratch_table(self, like: Tensor) -> Tensor:
         return scratch_table(like)
+
+
+def seed_prepare_reference(rows: Tensor, split: int, n: int, flag: Optional[Tensor] = None, slot: Optional[Tensor] = None):
+    """What lgc_seed_prepare computes, as torch ops on any device (seeds above LGC_SEED_MAX ids; the CPU test double)."""
+    dev = rows.device
+    m = rows.numel()
+    rows = torch.where((rows >= 0) & (rows < n), rows, torch.full_like(rows, -1))
+    rows_s, perm = torch.sort(rows, stable=True)
+    pos = torch.arange(m, device=dev)
+    head = torch.ones(m, dtype=torch.bool, device=dev)
+    head[1:] = rows_s[1:] != rows_s[:-1]
+    user = (rows_s >= 0) & (rows_s < split)
+    none = torch.full_like(rows_s, -1)
+    dest_item = torch.where(head & (rows_s >= split), rows_s, none)
+    dest_slot = torch.where(head & user, pos, none)
+    dest_user = torch.where(head & user, rows_s, none)
+    if flag is not None:
+        heads = rows_s[head & user]
+        flag[heads] = 1
+        slot[heads] = pos[head & user].to(torch.int32)
+    return rows_s, perm.to(torch.int32), dest_item, dest_slot, dest_user
 
 
 DEVICE_OPS = DeviceOps()
@@ -448,7 +545,9 @@ def seeded_sum(user_t, item_t, user_fwd, split: int, rows: Tensor, vals: Tensor,
       * the alpha_0 g term of the user rows is added to the seed rows afterwards instead of being read as a dense
         epilogue table by the last user step.
     ``user_t`` / ``item_t``: the user-row and item-row halves of A^T; ``user_fwd``: the user-row half of A (its columns
-    name the item rows of A^T that hold a seed user).  ``extra``: (rows, vals, scale) triples added to the result's rows
+    name the item rows of A^T that hold a seed user).  Negative row ids stand for "no row" (a rank of a partition parks
+    the pairs other ranks own there: a run of equal ids is summed by ONE lane group, so a thousand pairs clamped onto one
+    stand-in row cost 330 us).  ``extra``: (rows, vals, scale) triples added to the result's rows
     the same way -- the regulariser's gradient (LightGCN.regularization_loss), which upstream's autograd materialises as
     three dense [N, D] tables.
     On a rank of a partition (partition.py) the halves are the rank's LOCAL operators -- the user rows it owns, and the
@@ -461,16 +560,14 @@ def seeded_sum(user_t, item_t, user_fwd, split: int, rows: Tensor, vals: Tensor,
     dim = vals.size(1)
     dev = vals.device
     m = rows.numel()
-    rows_s, perm = torch.sort(rows, stable=True)
-    vals_s = vals[perm].contiguous()
-    pos = torch.arange(m, device=dev)
-    head = torch.ones(m, dtype=torch.bool, device=dev)
-    head[1:] = rows_s[1:] != rows_s[:-1]
-    is_user = rows_s < split
-    none = torch.full_like(rows_s, -1)
+    vals = vals.contiguous()
+    # one launch (lgc_seed_prepare): the sorted ids, the permutation, the three destination lists and -- for k > 0 -- the
+    # column map of the seeded pull (flag = 1, slot = position of the run's head, for every seed user)
+    flag, slot = _seed_map_buffers(dev, split) if k > 0 else (None, None)
+    rows_s, perm, dest_item, dest_slot, dest_user = ops.seed_prepare(rows, split, n, flag, slot)
     g_tab = torch.empty((n, dim), dtype=torch.float32, device=dev)         # only the item block is ever read
     g_tab[split:].zero_()
-    ops.segment_sum(rows_s, torch.where(is_user, none, rows_s), vals_s, g_tab)              # g[items]
+    ops.segment_sum(rows_s, dest_item, vals, g_tab, vals_index=perm)                        # g[items]
 
     def wait(work) -> None:
         if work is not None:
@@ -478,8 +575,9 @@ def seeded_sum(user_t, item_t, user_fwd, split: int, rows: Tensor, vals: Tensor,
 
     def finish(out: Tensor) -> Tensor:
         for e_rows, e_vals, e_scale in (extra or ()):
-            e_s, e_perm = torch.sort(e_rows, stable=True)
-            ops.segment_sum(e_s, e_s, e_vals[e_perm].contiguous(), out, scale=e_scale, accumulate=True)
+            e_s, e_perm, e_item, _, e_user = ops.seed_prepare(e_rows, split, n)
+            ops.segment_sum(e_s, torch.maximum(e_item, e_user), e_vals.contiguous(), out, scale=e_scale, accumulate=True,
+                            vals_index=e_perm)
         return out
 
     def new_result() -> Tensor:
@@ -491,16 +589,11 @@ def seeded_sum(user_t, item_t, user_fwd, split: int, rows: Tensor, vals: Tensor,
 
     if k == 0:
         out = torch.zeros((n, dim), dtype=torch.float32, device=dev)
-        ops.segment_sum(rows_s, rows_s, vals_s, out, scale=alphas[0])
+        ops.segment_sum(rows_s, torch.maximum(dest_item, dest_user), vals, out, scale=alphas[0], vals_index=perm)
         return finish(out)
     # compact table of the seed users: slot = position of the run's head
     gu = torch.empty((m, dim), dtype=torch.float32, device=dev)
-    user_head = is_user & head
-    ops.segment_sum(rows_s, torch.where(user_head, pos, none), vals_s, gu)
-    flag, slot = _seed_map_buffers(dev, split)
-    fidx = torch.where(is_user, rows_s, torch.full_like(rows_s, split))    # non-users park on the spare entry `split`
-    flag[fidx] = 1
-    slot[torch.where(user_head, rows_s, torch.full_like(rows_s, split))] = pos.to(torch.int32)
+    ops.segment_sum(rows_s, dest_slot, vals, gu, vals_index=perm)
     # Which item rows of A^T hold a seed user among their columns: row i of A^T has the columns {u : A[u, i] != 0}, so
     # the rows to read are the columns of the seed users' rows of the FORWARD operator A (not of A^T, whose user row u
     # lists {i : A[i, u] != 0} -- the same set only on a structurally symmetric edge list, which is never assumed).
@@ -517,7 +610,7 @@ def seeded_sum(user_t, item_t, user_fwd, split: int, rows: Tensor, vals: Tensor,
                         ops.seed_mark(user_fwd, rows_s, mark, 1)                # rows the pull has to read
                     ops.seed_pull(item_t, flag, slot, gu, nxt, mark)            # x_1[items] from the seed users
                 finally:
-                    flag[fidx] = 0                                              # flags and marks are all zero between steps
+                    ops.seed_flags(rows_s, split, flag, 0)                      # flags and marks are all zero between steps
                     if mark is not None:
                         ops.seed_mark(user_fwd, rows_s, mark, 0)
             else:
@@ -537,7 +630,7 @@ def seeded_sum(user_t, item_t, user_fwd, split: int, rows: Tensor, vals: Tensor,
                 wait(pending[k])
                 ops.lincomb(out[split:], [(alphas[l], tables[l][split:]) for l in range(0, k + 1)])
                 # + alpha_0 g on the seed users (each such row is owned by one lane group: read, add, write)
-                ops.segment_sum(rows_s, torch.where(is_user, rows_s, none), vals_s, out, scale=alphas[0], accumulate=True)
+                ops.segment_sum(rows_s, dest_user, vals, out, scale=alphas[0], accumulate=True, vals_index=perm)
     return finish(out)
 
 
@@ -558,32 +651,24 @@ class _ScoresFromTable(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, w: Tensor, graph: PropGraph, alphas: tuple, idx0: Tensor, idx1: Tensor, hook: Optional[RegHook]):
-        lib = _native.load()
         idx0, idx1 = idx0.contiguous(), idx1.contiguous()
         n_nodes = w.size(0)
         # only the rows the pairs name are read below (clamped like the gathers that follow, so that every row that is
         # gathered has been computed): the last user step is restricted to them
-        need = torch.cat([idx0, idx1]).clamp(0, n_nodes - 1)
-        emb = _layer_sum(graph, w.detach(), alphas, transpose=False, final_rows=need)
-        scores = torch.empty(idx0.numel(), dtype=torch.float32, device=emb.device)
-        with torch.cuda.device(emb.device):
-            code = lib.lgc_pair_dot(_native.ptr(emb), emb.stride(0), emb.size(1), emb.size(0), _native.ptr(idx0),
-                                    _native.ptr(idx1), idx0.numel(), _native.ptr(scores), _native.ptr(_status(emb.device)),
-                                    _native.stream_of(emb.device))
-        _native.check(code, "lgc_pair_dot")
-        _snapshot_status(emb.device)
-        n = emb.size(0)
-        ok = (idx0 >= 0) & (idx0 < n) & (idx1 >= 0) & (idx1 < n)       # invalid pairs score NaN and carry no gradient
-        i0, i1 = idx0.clamp(0, n - 1), idx1.clamp(0, n - 1)
-        ctx.save_for_backward(emb[i0], emb[i1], i0, i1, ok)
-        ctx.graph, ctx.alphas, ctx.n, ctx.hook, ctx.width = graph, alphas, n, hook, emb.size(1)
+        rows = torch.cat([idx0, idx1])
+        emb = _layer_sum(graph, w.detach(), alphas, transpose=False, final_rows=rows.clamp(0, n_nodes - 1))
+        # one launch: the scores, the two gathered rows of every pair and a validity byte (an invalid pair scores NaN,
+        # keeps zero rows and carries no gradient)
+        scores, e0, e1, ok = DEVICE_OPS.pair_scores_rows(emb, idx0, idx1)
+        ctx.save_for_backward(e0, e1, rows, ok)
+        ctx.graph, ctx.alphas, ctx.n, ctx.hook, ctx.width = graph, alphas, emb.size(0), hook, emb.size(1)
         ctx.set_materialize_grads(False)                                # an unused output arrives as None, not as zeros
         return scores, torch.zeros((), dtype=torch.float32, device=emb.device)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_scores: Tensor, grad_token: Optional[Tensor]):
-        e0, e1, i0, i1, ok = ctx.saved_tensors
+        e0, e1, rows, ok = ctx.saved_tensors
         hook = ctx.hook
         extra = []
         if hook is not None:
@@ -595,11 +680,11 @@ class _ScoresFromTable(torch.autograd.Function):
             out = torch.zeros((ctx.n, ctx.width), dtype=torch.float32, device=e0.device)
             for r, v, scale in extra:
                 r_s, perm = torch.sort(r, stable=True)
-                segment_sum(r_s, r_s, v[perm].contiguous(), out, scale=scale, accumulate=True)
+                segment_sum(r_s, r_s, v.contiguous(), out, scale=scale, accumulate=True, vals_index=perm.to(torch.int32))
             return out, None, None, None, None, None
-        gs = torch.where(ok, grad_scores, torch.zeros_like(grad_scores)).unsqueeze(1)
-        rows = torch.cat([i0, i1])                                       # pairs that share a node simply add up
-        vals = torch.cat([gs * e1, gs * e0])                             # d score / d out[i0] = e1, d / d out[i1] = e0
+        # pairs that share a node simply add up; d score / d out[i0] = e1, d / d out[i1] = e0; an invalid pair's id is
+        # outside the table: "no row" for the seed
+        vals = DEVICE_OPS.pair_seed_vals(grad_scores, ok, None, e0, e1)
         return seeded_transpose_sum(ctx.graph, rows, vals, ctx.alphas, ctx.n, extra), None, None, None, None, None
 
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LGC_ABI_VERSION 10
+#define LGC_ABI_VERSION 11
 
 /* argument errors (negative return values) */
 #define LGC_E_INVAL      (-1)  /* null pointer, negative size, bad flag                    */
@@ -294,8 +294,46 @@ int lgc_hop_exchange(const lgc_operator *item_op, const lgc_operator *user_op, i
  * `key_sorted` int64 [n] is sorted; position t is a head when key[t] != key[t - 1]; for every head with 0 <= dest[t] < y_rows
  *   y[dest[t]] = (accumulate ? y[dest[t]] : 0) + scale * (vals[t] + vals[t + 1] + ... over the run, in that order)
  * vals fp32 [n, dim] dense.  One lane group owns a destination row: no atomics, the same bits on every run. */
-int lgc_segment_sum(const int64_t *key_sorted, const int64_t *dest, const float *vals, int64_t n, float scale, float *y,
-                    int64_t y_stride, int64_t y_rows, int32_t dim, int32_t accumulate, void *stream);
+int lgc_segment_sum(const int64_t *key_sorted, const int64_t *dest, const float *vals, const int32_t *vals_index, int64_t n,
+                    float scale, float *y, int64_t y_stride, int64_t y_rows, int32_t dim, int32_t accumulate, void *stream);
+/* vals_index (int32 [n] or NULL): the value row of sorted position t is vals[vals_index[t]] -- the permutation a sort
+ * returned, so that the value table is never copied into sorted order. */
+
+/* ---------------------------------------------------------------------------------------
+ * The glue of one training step (src/train_lightgcn.py:137-147) around the propagation, as a handful of launches instead
+ * of the ~150 small torch kernels the same arithmetic costs on the host side: on a rank of an 8-way partition the step was
+ * bound by the host's launch rate (3.0 ms wall for 1.5 ms of kernels).
+ *
+ * lgc_pair_dot_rows  lgc_pair_dot that also keeps what autograd's backward of src/lightgcn.py:123-125 needs: the two
+ *                    gathered rows of every pair (rows0, rows1: fp32 [n_pairs, dim] dense, or NULL) and a validity byte
+ *                    (ok: uint8 [n_pairs] or NULL; 0 for an out-of-range pair, whose rows are zeros and whose score is NaN).
+ * lgc_bpr_loss       `recommendation_loss(pos, neg, 0) * size` (src/lightgcn.py:262-286, src/train_lightgcn.py:141) for
+ *                    scores [2 * n_triples] = [pos | neg] and its gradient: loss[0] = -sum_{mask} log sigmoid(pos - neg) /
+ *                    size, grad [2 * n_triples].  mask (uint8 [n_triples] or NULL = all): the triples this caller owns --
+ *                    a rank of a partition scores the triples of its own users; `size` is the GLOBAL batch size.
+ * lgc_pair_seed_vals the sparse gradient of the scores with respect to the propagated table, as rows of a value table:
+ *                    vals[m] = g_m * rows1[m], vals[n_pairs + m] = g_m * rows0[m], g_m = mask[m] ? grad_scores[m] *
+ *                    (*grad_scale) : 0 (grad_scale: DEVICE scalar or NULL; mask uint8 [n_pairs] or NULL).
+ * lgc_seed_prepare   sorts the m <= LGC_SEED_MAX node ids `rows` (int64; ids outside [0, n_nodes) count as "no row" and
+ *                    come out as -1, first) and derives, per sorted position t: rows_sorted[t]; perm[t] (int32, the input
+ *                    position: a stable sort); dest_item[t] = the row if t heads a run of an item row (row >= split) else
+ *                    -1; dest_slot[t] = t, dest_user[t] = the row if t heads a run of a user row (row < split) else -1 --
+ *                    the three destination lists of lgc_segment_sum for the item block of the seed table, the compact
+ *                    table of seed users and the user rows of the result.  With col_flag / col_slot (both or neither):
+ *                    col_flag[row] = 1, col_slot[row] = t for every user head -- lgc_seed_pull's column map.
+ * lgc_seed_flags     col_flag[row] = value for the user rows of a sorted list (value 0 takes the flags back).
+ * ------------------------------------------------------------------------------------- */
+#define LGC_SEED_MAX 8192
+int lgc_pair_dot_rows(const float *emb, int64_t stride, int32_t dim, int64_t n_nodes, const int64_t *idx0, const int64_t *idx1,
+                      int64_t n_pairs, float *scores, float *rows0, float *rows1, uint8_t *ok, int32_t *status, void *stream);
+int lgc_bpr_loss(const float *scores, const uint8_t *mask, int64_t n_triples, int64_t size, float *loss, float *grad,
+                 void *stream);
+int lgc_pair_seed_vals(const float *grad_scores, const uint8_t *mask, const float *grad_scale, const float *rows0,
+                       const float *rows1, int64_t n_pairs, int32_t dim, float *vals, void *stream);
+int lgc_seed_prepare(const int64_t *rows, int64_t m, int64_t split, int64_t n_nodes, int64_t *rows_sorted, int32_t *perm,
+                     int64_t *dest_item, int64_t *dest_slot, int64_t *dest_user, uint8_t *col_flag, int32_t *col_slot,
+                     void *stream);
+int lgc_seed_flags(const int64_t *rows_sorted, int64_t m, int64_t split, uint8_t *col_flag, int32_t value, void *stream);
 
 /* Seeded pull (first hop of the backward pass, loss.backward() at src/train_lightgcn.py:146): the incoming gradient has
  * non-zero rows only at a few thousand seed columns, given as a compact table.  The hop of lgc_spmm over rows

@@ -334,8 +334,8 @@ def test_argument_errors_of_the_round3_entry_points():
     """lgc_segment_sum, lgc_seed_pull, lgc_seed_mark, lgc_adam_step, lgc_hop_exchange: bad arguments are refused before any launch."""
     lib = _native.load()
     one, two = ctypes.c_void_p(256), ctypes.c_void_p(512)
-    seg = lambda **kw: lib.lgc_segment_sum(kw.get("key", one), one, one, kw.get("n", 8), 1.0, kw.get("y", two), kw.get("ys", 64),
-                                           100, kw.get("dim", 64), 0, None)
+    seg = lambda **kw: lib.lgc_segment_sum(kw.get("key", one), one, one, None, kw.get("n", 8), 1.0, kw.get("y", two),
+                                           kw.get("ys", 64), 100, kw.get("dim", 64), 0, None)
     assert seg(y=None) == -1 and seg(n=-1) == -1 and seg(dim=0) == -1 and seg(dim=300) == -1 and seg(ys=32) == -1
     assert seg(key=None) == -1 and seg(n=0) == 0                                  # nothing to do is not an error
     pull = lambda **kw: lib.lgc_seed_pull(one, one, 0, 4, 32, None, kw.get("n_chunks", 0), None, 0, None, kw.get("flag", one),
@@ -360,6 +360,28 @@ def test_argument_errors_of_the_round3_entry_points():
     assert lib.lgc_hop_exchange(ctypes.byref(op), ctypes.byref(op), 100, one, 64, two, 64, None, 0, 1.0, 0.0, 64, 90, 20, 1, cb,
                                 None, None) == -1                                  # exchanged block beyond the table
     assert lib.lgc_hop_exchange(None, ctypes.byref(op), 100, one, 64, two, 64, None, 0, 1.0, 0.0, 64, 50, 20, 1, cb, None, None) == -1
+
+
+def test_argument_errors_of_the_round4_entry_points():
+    """lgc_seed_prepare, lgc_seed_flags, lgc_pair_dot_rows, lgc_pair_seed_vals, lgc_bpr_loss: refused before any launch."""
+    lib = _native.load()
+    one, two = ctypes.c_void_p(256), ctypes.c_void_p(512)
+    prep = lambda **kw: lib.lgc_seed_prepare(kw.get("rows", one), kw.get("m", 8), kw.get("split", 4), kw.get("n", 10), one, one,
+                                             kw.get("di", one), one, one, kw.get("flag", None), kw.get("slot", None), None)
+    assert prep(m=-1) == -4 and prep(m=8193) == -4 and prep(rows=None) == -1 and prep(di=None) == -1 and prep(split=11) == -1
+    assert prep(flag=one) == -1 and prep(slot=one) == -1 and prep(m=0) == 0       # flag and slot: both or neither
+    flags = lambda **kw: lib.lgc_seed_flags(kw.get("rows", one), kw.get("m", 8), 4, kw.get("flag", two), kw.get("value", 0), None)
+    assert flags(rows=None) == -1 and flags(flag=None) == -1 and flags(m=-1) == -1 and flags(value=256) == -1 and flags(m=0) == 0
+    pdr = lambda **kw: lib.lgc_pair_dot_rows(kw.get("emb", one), kw.get("stride", 64), kw.get("dim", 64), 100, kw.get("i0", one),
+                                             one, kw.get("m", 8), kw.get("scores", two), None, None, None, kw.get("status", two), None)
+    assert pdr(emb=None) == -1 and pdr(stride=32) == -1 and pdr(dim=0) == -1 and pdr(status=None) == -1 and pdr(i0=None) == -1
+    assert pdr(scores=None) == -1 and pdr(m=-1) == -1 and pdr(m=0) == 0
+    psv = lambda **kw: lib.lgc_pair_seed_vals(kw.get("g", one), None, None, kw.get("r0", one), one, kw.get("m", 8), kw.get("dim", 64),
+                                              kw.get("vals", two), None)
+    assert psv(g=None) == -1 and psv(r0=None) == -1 and psv(vals=None) == -1 and psv(m=-1) == -1 and psv(dim=0) == -1 and psv(m=0) == 0
+    bpr = lambda **kw: lib.lgc_bpr_loss(kw.get("s", one), None, kw.get("b", 8), kw.get("size", 8), kw.get("loss", two), kw.get("grad", two),
+                                        None)
+    assert bpr(loss=None) == -1 and bpr(s=None) == -1 and bpr(grad=None) == -1 and bpr(b=-1) == -1 and bpr(size=0) == -1
 
 
 def test_saved_graph_validation_rejects_tampered_tensors():

@@ -1167,7 +1167,7 @@ def test_routed_regulariser_takes_every_index_form_upstream_takes(device, monkey
     vals = torch.ones((4, dim), device=device)
     for bad in (dict(key=key.cpu()), dict(key=key.int()), dict(dest=key[:3]), dict(vals=vals[:, :8]), dict(vals=vals.double()),
                 dict(vals=vals.cpu()), dict(out=out.double()), dict(out=out.t())):
-        kw = dict(key=key, dest=key, vals=vals, out=out, **bad)
+        kw = {**dict(key=key, dest=key, vals=vals, out=out), **bad}
         with pytest.raises((TypeError, lg._native.NativeLibraryError)):
             propagate.segment_sum(kw["key"], kw["dest"], kw["vals"], kw["out"])
 
@@ -1209,6 +1209,83 @@ def test_adam_over_row_ranges_and_foreign_state(device, dim):
     pa.grad = torch.zeros(rows - 1, dim, device=device)
     with pytest.raises(RuntimeError):
         oa.step()
+
+
+@pytest.mark.parametrize("m", [1, 5, 777, 4096, 8192, 9000])
+def test_seed_prepare_is_a_stable_sort_with_the_destination_lists(device, m):
+    """lgc_seed_prepare (one workgroup, bitonic sort in LDS) against the same steps in torch: sorted ids with "no row"
+    for ids outside the table, the stable permutation, the three destination lists and the pull's column map; above
+    LGC_SEED_MAX ids the torch steps run instead (m = 9000)."""
+    from gnn_ecommerce_amd import propagate
+    gen = torch.Generator().manual_seed(m)
+    n, split = 5000, 4200
+    rows = torch.randint(-3, n + 3, (m,), generator=gen)
+    rows[: m // 3] = rows[0]                                          # a long run of one id
+    rows = rows[torch.randperm(m, generator=gen)].to(device)
+    flag = torch.zeros(split + 1, dtype=torch.uint8, device=device)
+    slot = torch.full((split + 1,), -7, dtype=torch.int32, device=device)
+    got = propagate.DEVICE_OPS.seed_prepare(rows, split, n, flag, slot)
+    flag_r, slot_r = torch.zeros_like(flag), torch.full_like(slot, -7)
+    want = propagate.seed_prepare_reference(rows, split, n, flag_r, slot_r)
+    for g, w, name in zip(got, want, ("rows_sorted", "perm", "dest_item", "dest_slot", "dest_user")):
+        assert g.dtype == w.dtype and torch.equal(g, w), name
+    assert torch.equal(flag, flag_r) and torch.equal(slot, slot_r) and int(flag.sum()) > 0
+    propagate.DEVICE_OPS.seed_flags(got[0], split, flag, 0)
+    assert int(flag.sum()) == 0
+    # the permutation feeds lgc_segment_sum directly: the value table stays unsorted
+    vals = torch.randn(m, 64, generator=gen).to(device)
+    a, b = torch.zeros(n, 64, device=device), torch.zeros(n, 64, device=device)
+    dest = torch.maximum(got[2], got[4])
+    propagate.segment_sum(got[0], dest, vals, a, scale=0.5, vals_index=got[1])
+    propagate.segment_sum(got[0], dest, vals[got[1].long()].contiguous(), b, scale=0.5)
+    assert torch.equal(a, b)
+    ref = torch.zeros(n, 64, dtype=torch.float64)
+    ok = ((rows >= 0) & (rows < n)).cpu()
+    ref.index_add_(0, rows.cpu()[ok], vals.cpu().double()[ok] * 0.5)
+    assert rel_fro(a.cpu(), ref) <= 1e-6
+
+
+@pytest.mark.parametrize("dim", [64, 90, 7])
+def test_training_glue_kernels_match_torch(device, dim):
+    """lgc_pair_dot_rows, lgc_bpr_loss, lgc_pair_seed_vals -- the launches that replace the host-side glue of a training
+    step -- against the torch expressions they stand for (src/lightgcn.py:123-125, :262-286, and autograd's backward)."""
+    from gnn_ecommerce_amd import propagate
+    ops = propagate.DEVICE_OPS
+    gen = torch.Generator().manual_seed(dim)
+    n, b = 900, 257
+    emb = torch.randn(n, dim, generator=gen)
+    idx0 = torch.randint(0, n, (2 * b,), generator=gen)
+    idx1 = torch.randint(0, n, (2 * b,), generator=gen)
+    idx1[3], idx0[11] = n + 2, -1                                      # two invalid pairs
+    scores, e0, e1, ok = ops.pair_scores_rows(emb.to(device), idx0.to(device), idx1.to(device))
+    valid = (idx0 >= 0) & (idx0 < n) & (idx1 >= 0) & (idx1 < n)
+    assert torch.equal(ok.cpu().bool(), valid) and torch.isnan(scores[3]) and torch.isnan(scores[11])
+    w0, w1 = emb[idx0.clamp(0, n - 1)] * valid.view(-1, 1), emb[idx1.clamp(0, n - 1)] * valid.view(-1, 1)
+    assert torch.equal(e0.cpu(), w0) and torch.equal(e1.cpu(), w1)
+    assert torch.allclose(scores.cpu()[valid], (w0 * w1).sum(-1)[valid], rtol=1e-5, atol=1e-5)
+    with pytest.raises(IndexError):
+        lg.check_index_status()
+    # BPR term and its gradient, with and without an ownership mask, against autograd
+    s = (torch.randn(2 * b, generator=gen) * 3).requires_grad_(True)
+    for mask in (None, torch.rand(b, generator=gen) < 0.4):
+        on = torch.ones(b, dtype=torch.bool) if mask is None else mask
+        ref = -(torch.nn.functional.logsigmoid(s[:b] - s[b:]) * on).sum() / 1024
+        (g_ref,) = torch.autograd.grad(ref, s)
+        loss, grad = ops.bpr_loss(s.detach().to(device), None if mask is None else mask.to(torch.uint8).to(device), 1024)
+        assert abs(loss.item() - ref.item()) <= 1e-6 * abs(ref.item()) and rel_fro(grad.cpu().view(1, -1), g_ref.view(1, -1)) <= 1e-6
+    # with size = B and no mask it is recommendation_loss(pos, neg, 0) * B of the reference's step
+    model_loss = lg.LightGCN(10, 8, 1).recommendation_loss(s[:b].detach(), s[b:].detach(), 0) * b
+    loss, _ = ops.bpr_loss(s.detach().to(device), None, b)
+    assert abs(loss.item() - model_loss.item()) <= 1e-6 * abs(model_loss.item())
+    # seed values: g * rows1 | g * rows0, masked, scaled by a device scalar
+    gs = torch.randn(2 * b, generator=gen)
+    mask2 = (torch.rand(2 * b, generator=gen) < 0.7)
+    scale = torch.tensor(0.37)
+    vals = ops.pair_seed_vals(gs.to(device), mask2.to(torch.uint8).to(device), scale.to(device), e0, e1)
+    g = (gs * mask2 * scale).view(-1, 1)
+    assert rel_fro(vals.cpu(), torch.cat([g * w1, g * w0])) <= 1e-6
+    vals = ops.pair_seed_vals(gs.to(device), None, None, e0, e1)
+    assert torch.equal(vals.cpu(), torch.cat([gs.view(-1, 1) * w1, gs.view(-1, 1) * w0]))
 
 
 def test_invalidate_after_an_untracked_write_and_late_index_errors(device):

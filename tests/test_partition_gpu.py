@@ -133,6 +133,7 @@ def _train_worker(rank, world, port, q, backend="gloo"):
         res = {"world": dist.get_world_size(), "backend": dist.get_backend()}
         for seeded in (True, False):
             partition.SEEDED_STEP = seeded
+            lg.propagate.SEED_ROWS_FACTOR = 0                   # the seeded node whatever the table size (21,500 rows here)
             wp = w0.clone().requires_grad_(True)
             local, gbpr, greg = partitioned_bpr_loss(pp, wp, [0.25] * 4, users, pos, neg, decay, zero_foreign_rows=not seeded)
             res[("seeded_" if seeded else "") + "node"] = _uses_node(local.grad_fn, "PartitionedScores")
