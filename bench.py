@@ -51,6 +51,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-deep", action="store_true", help="skip the configs[2] (D=90, K=5) measurement that rides "
                     "along on the default single-GPU run")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step measurements (configs[4]'s step on one "
+                    "GPU at D=64/K=3 and D=90/K=5, and its one-step CPU baseline) of the default single-GPU run")
+    ap.add_argument("--no-rank-local", action="store_true", help="skip the rank-local measurement (one rank of an 8-way "
+                    "partition on this GPU, collectives stubbed)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = auto)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
                     "to rehearse the N > 1 path with several ranks on ONE GPU)")
@@ -102,6 +106,130 @@ def cpu_baseline(graph, layers, dim, threads=0):
                                   "value": graph.nnz * layers / dt2, "unit": "edges/s", "cores": cores,
                                   "seconds": round(dt2, 3)}
     return out
+
+
+def training_step_bench(graph, ei, ew, dim, layers, steps, warmup, batch=1024, lr=0.005, decay=1e-4):
+    """BASELINE.json configs[4]'s step on ONE GPU: the loop body of src/train_lightgcn.py:130-147 (zero_grad -> labels ->
+    forward -> bpr * size + reg -> backward -> Adam) with B = 1024 on the full graph, (u, i+, i-) drawn uniformly with a
+    seeded generator (the pandas sampler is out of scope).  The calls are the reference's own --
+    ``model(edge_index, labels, edge_weight)``, ``recommendation_loss``, ``regularization_loss``, ``loss.backward()``,
+    ``optimizer.step()``, three ``.item()`` -- on the drop-in classes."""
+    import gnn_ecommerce_amd as lg
+    from gnn_ecommerce_amd.optim import Adam as HipAdam
+    dev = ei.device
+    torch.manual_seed(SEED)
+    model = lg.LightGCN(graph.num_nodes, dim, layers).to(dev)
+    opt = HipAdam(model.parameters(), lr)
+    gen = torch.Generator().manual_seed(SEED)
+
+    def step():
+        opt.zero_grad()
+        u = torch.randint(0, graph.n_users, (batch,), generator=gen).to(dev)
+        p = (torch.randint(0, graph.n_items, (batch,), generator=gen) + graph.n_users).to(dev)
+        n = (torch.randint(0, graph.n_items, (batch,), generator=gen) + graph.n_users).to(dev)
+        labels = torch.stack((torch.cat([u, u]), torch.cat([p, n])))
+        out = model(ei, labels, ew)
+        bpr = model.recommendation_loss(out[:batch], out[batch:], 0) * batch
+        reg = lg.regularization_loss(model.embedding.weight, batch, u, p, n, decay)
+        loss = bpr + reg
+        loss.backward()
+        opt.step()
+        return bpr.item(), reg.item(), loss.item()
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        vals = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    del model, opt
+    return {"value": 1.0 / dt, "unit": "steps/s", "ms_per_step": dt * 1e3, "steps": steps, "warmup": warmup, "loss": vals[2]}
+
+
+def training_step_cpu(graph, dim, layers, threads=0, batch=1024, lr=0.005, decay=1e-4):
+    """The same step on this host through the oracle's restatement of the reference route (unsorted COO, per-layer
+    gcn_norm, gather -> scale -> index_add_, autograd, dense torch Adam): ONE step, untimed allocations included."""
+    from oracle import lightgcn_oracle as oracle
+    from gnn_ecommerce_amd import synth
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    cores = threads if threads > 0 else min(avail, CPU_THREADS_DEFAULT)
+    torch.set_num_threads(cores)
+    ei, ew = graph.coo()
+    w = torch.nn.Parameter(synth.xavier_table(graph.num_nodes, dim, SEED))
+    opt = torch.optim.Adam([w], lr)
+    gen = torch.Generator().manual_seed(SEED)
+    u = torch.randint(0, graph.n_users, (batch,), generator=gen)
+    p = torch.randint(0, graph.n_items, (batch,), generator=gen) + graph.n_users
+    n = torch.randint(0, graph.n_items, (batch,), generator=gen) + graph.n_users
+    t0 = time.perf_counter()
+    opt.zero_grad()
+    loss = oracle.train_step_loss(w, oracle.default_alpha(layers), ei, ew, u, p, n, layers, decay)[3]
+    loss.backward()
+    opt.step()
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"ONE step (forward + backward + dense Adam, B={batch}, D={dim}, K={layers}) of the same graph on {cpu_model()}, "
+                      f"{cores} threads: {dt:.1f} s"}
+
+
+def rank_local_bench(graph, ei, ew, dim, layers, world, ranks, single_hop_s):
+    """What ONE rank of a ``world``-way partition computes per hop, measured on this one GPU with every collective
+    stubbed out (local work only: what RCCL adds can only be measured on a multi-GPU node) -- and the ceiling it puts on
+    the speed-up over one GPU.  Also the rank-local training step (partition.partitioned_bpr_loss + Adam over the rows
+    the rank owns), same stub."""
+    import torch.distributed as dist
+    from gnn_ecommerce_amd import partition, synth
+    from gnn_ecommerce_amd.optim import Adam as HipAdam
+    real_all_reduce = dist.all_reduce
+    dist.all_reduce = lambda *a, **k: None
+    try:
+        dev = ei.device
+        alphas = tuple([1.0 / (layers + 1)] * (layers + 1))
+        x0 = synth.xavier_table(graph.num_nodes, dim, SEED, dev)
+        hop_us, train_ms = [], []
+        for r in ranks:
+            pp = partition.PartitionedPropagator(ei, ew, graph.n_users, graph.n_items, r, world)
+            for _ in range(3):
+                pp.propagate_sum(x0, alphas)
+            torch.cuda.synchronize()
+            reps = 20
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                pp.propagate_sum(x0, alphas)
+            torch.cuda.synchronize()
+            hop_us.append((time.perf_counter() - t0) / reps / layers * 1e6)
+            w = torch.nn.Parameter(x0.clone())
+            opt = HipAdam([w], 0.005, row_ranges=pp.owned_row_ranges())
+            gen = torch.Generator().manual_seed(SEED)
+
+            def step():
+                opt.zero_grad()
+                u = torch.randint(0, graph.n_users, (1024,), generator=gen).to(dev)
+                p = (torch.randint(0, graph.n_items, (1024,), generator=gen) + graph.n_users).to(dev)
+                n = (torch.randint(0, graph.n_items, (1024,), generator=gen) + graph.n_users).to(dev)
+                local, gbpr, greg = partition.partitioned_bpr_loss(pp, w, alphas, u, p, n, 1e-4, zero_foreign_rows=False)
+                local.backward()
+                opt.step()
+                return gbpr.item(), greg.item()
+
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                step()
+            torch.cuda.synchronize()
+            train_ms.append((time.perf_counter() - t0) / reps * 1e3)
+            del pp, w, opt
+        worst = max(hop_us)
+        return {"world": world, "ranks_measured": list(ranks), "us_per_hop": worst, "us_per_hop_by_rank": hop_us,
+                "ceiling_x": single_hop_s * 1e6 / worst, "train_ms_per_step": max(train_ms),
+                "what": "local work of one rank per hop / per training step on this one GPU, every all-reduce stubbed out; "
+                        "ceiling_x = this run's single-GPU hop time / us_per_hop (no exchange cost in it)"}
+    finally:
+        dist.all_reduce = real_all_reduce
 
 
 def workload_name(args, world: int) -> str:
@@ -188,6 +316,7 @@ def main():
         make_step = lambda x0, alphas: (lambda: pp.propagate_sum(x0, alphas))
         parallelism = (f"user-range x{world}, items replicated, all-reduce [n_items,D]/hop over {args.backend}"
                        + ("" if args.backend == "nccl" else " (rehearsal, not RCCL)"))
+    keep_coo = (ei, ew)
     del ei, ew
 
     def fence():
@@ -249,6 +378,22 @@ def main():
         deep_plan = time.perf_counter() - t0
         deep_steps = max(5, args.steps // 2)
         deep_m = measure(90, 5, deep_steps, args.warmup)
+    default_run = world == 1 and args.config == "cosmetics" and (args.layers, args.dim) == (LAYERS, DIM)
+    train_lines, rank_local = [], None
+    if default_run and not args.no_train:
+        for t_dim, t_layers, t_steps, with_cpu in ((64, 3, max(20, args.steps), True), (90, 5, max(10, args.steps // 2), False)):
+            t = training_step_bench(graph, keep_coo[0], keep_coo[1], t_dim, t_layers, t_steps, args.warmup)
+            entry = {"workload": f"configs[4]'s step on ONE GPU: B=1024, emb_dim {t_dim}, {t_layers} LGConv layers, forward + backward "
+                                 "(seeded) + Adam (optim.Adam, one pass) on the full graph, uniform seeded triples"
+                                 + ("" if (t_dim, t_layers) == (64, 3) else " -- the reference's own hyper-parameters "
+                                    "(src/train_lightgcn.py:47-53)"),
+                     "dtype": "f32", **t}
+            if with_cpu and not args.no_cpu_baseline:
+                entry["cpu_baseline"] = training_step_cpu(graph, t_dim, t_layers, args.cpu_threads)
+            train_lines.append(entry)
+    if default_run and not args.no_rank_local:
+        rank_local = rank_local_bench(graph, keep_coo[0], keep_coo[1], args.dim, args.layers, 8, (0, 5), main_m["hop_mean_s"])
+    del keep_coo
     if rank == 0:
         elapsed = main_m["elapsed"]
         line = {
@@ -281,6 +426,10 @@ def main():
                 "plan_build_s": round(deep_plan, 3),
                 "roofline": roofline_of(deep_m, 90, "one hop: k_sweep_wide + k_sweep_combine, k_apply_fused<2> (two DPP rows "
                                                     "per table row, 96-float internal row stride)")}]
+        if train_lines:
+            line.setdefault("other_configs", []).extend(train_lines)
+        if rank_local is not None:
+            line["rank_local"] = rank_local
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(graph, args.layers, args.dim, args.cpu_threads)
         print(json.dumps(line), flush=True)

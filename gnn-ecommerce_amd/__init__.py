@@ -14,6 +14,7 @@ from .lightgcn import BPRLoss, LightGCN, regularization_loss
 from .propagate import check_index_status, hop, pair_dot, propagate_sum
 from .sampler import TripleSampler
 from . import ingest, serving
+from .trainer import PartitionedTrainer
 
 __all__ = ["LightGCN", "BPRLoss", "LGConv", "PropGraph", "get_graph", "clear_cache", "build_row_plan",
-           "propagate_sum", "hop", "pair_dot", "check_index_status", "TripleSampler", "regularization_loss", "_native"]
+           "propagate_sum", "hop", "pair_dot", "check_index_status", "TripleSampler", "regularization_loss", "PartitionedTrainer", "_native"]

@@ -103,6 +103,7 @@ SIGNATURES = {
     "lgc_seed_mark": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p]),
     "lgc_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
                               c_float, c_void_p]),
+    "lgc_adam_step_hp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "lgc_lincomb": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p]),
     "lgc_mask_topk": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
                               c_void_p, c_void_p, c_void_p]),

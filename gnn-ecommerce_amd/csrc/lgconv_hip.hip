@@ -1416,7 +1416,7 @@ __global__ __launch_bounds__(kSeedBlock) void k_seed_prepare(const int64_t *__re
     for (int size = 2; size <= n2; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             for (int t = threadIdx.x; t < (n2 >> 1); t += kSeedBlock) {
-                const int lo = ((t / stride) * stride * 2) + (t % stride), hi = lo + stride;
+                const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1)), hi = lo | stride;
                 const bool up = (lo & size) == 0;
                 const unsigned long long a = key[lo], b = key[hi];
                 if ((a > b) == up) { key[lo] = b; key[hi] = a; }
@@ -1558,7 +1558,10 @@ __global__ void k_lincomb(float *__restrict__ y, int64_t y_stride, LincombArgs a
 // (1 - beta1) and (1 - beta2) come from the host, rounded from double like torch's scalars: 1.0f - 0.999f is 4.7e-5 off.
 __global__ __launch_bounds__(kBlock) void k_adam(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m,
                                                 float *__restrict__ v, int64_t n4, int64_t n, float beta2, float omb1, float omb2,
-                                                float eps, float step_size, float bc2_sqrt) {
+                                                float eps, float step_size, float bc2_sqrt, const float *__restrict__ hyper) {
+    if (hyper != nullptr) {   // lgc_adam_step_hp: the step's scalars live in device memory (a captured launch is replayed with
+        omb1 = hyper[0]; beta2 = hyper[1]; omb2 = hyper[2]; eps = hyper[3]; step_size = hyper[4]; bc2_sqrt = hyper[5];   // new values)
+    }
     auto one = [&](float &wi, float gi, float &mi, float &vi) {
         mi = mi + (gi - mi) * omb1;
         vi = beta2 * vi + omb2 * gi * gi;
@@ -2806,9 +2809,26 @@ int lgc_lincomb(float *y, int64_t y_stride, const float *const *src, const int64
     return (int)hipGetLastError();
 }
 
+static int adam_launch(float *w, const float *g, float *m, float *v, int64_t n, float one_minus_beta1, float beta2,
+                       float one_minus_beta2, float eps, float step_size, float bias_correction2_sqrt, const float *hyper,
+                       void *stream_);
+
 int lgc_adam_step(float *w, const float *g, float *m, float *v, int64_t n, float one_minus_beta1, float beta2,
                   float one_minus_beta2, float eps, float step_size, float bias_correction2_sqrt, void *stream_) {
-    if (!w || !g || !m || !v || n < 0 || !(bias_correction2_sqrt > 0.0f)) return LGC_E_INVAL;
+    if (!(bias_correction2_sqrt > 0.0f)) return LGC_E_INVAL;
+    return adam_launch(w, g, m, v, n, one_minus_beta1, beta2, one_minus_beta2, eps, step_size, bias_correction2_sqrt, nullptr,
+                       stream_);
+}
+
+int lgc_adam_step_hp(float *w, const float *g, float *m, float *v, int64_t n, const float *hyper, void *stream_) {
+    if (!hyper) return LGC_E_INVAL;
+    return adam_launch(w, g, m, v, n, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, hyper, stream_);
+}
+
+static int adam_launch(float *w, const float *g, float *m, float *v, int64_t n, float one_minus_beta1, float beta2,
+                       float one_minus_beta2, float eps, float step_size, float bias_correction2_sqrt, const float *hyper,
+                       void *stream_) {
+    if (!w || !g || !m || !v || n < 0) return LGC_E_INVAL;
     // dword-aligned, and all four at the same offset inside a 16-byte line (a row range of same-shaped tables whose rows
     // are not whole float4s, e.g. rows [lo, hi) of a [N, 90] table): the first elements up to the line are done one by one
     const uintptr_t mis = reinterpret_cast<uintptr_t>(w) & 15;
@@ -2820,14 +2840,14 @@ int lgc_adam_step(float *w, const float *g, float *m, float *v, int64_t n, float
     const int64_t head = std::min<int64_t>(n, (int64_t)((16 - mis) & 15) / 4);
     if (head > 0)
         hipLaunchKernelGGL(k_adam, dim3(1), dim3(kBlock), 0, stream, w, g, m, v, (int64_t)0, head, beta2, one_minus_beta1,
-                           one_minus_beta2, eps, step_size, bias_correction2_sqrt);
+                           one_minus_beta2, eps, step_size, bias_correction2_sqrt, hyper);
     w += head; g += head; m += head; v += head; n -= head;
     if (n == 0) return (int)hipGetLastError();
     const int64_t n4 = n / 4;
     const int64_t blocks = std::max<int64_t>(ceil_div(n4, (int64_t)kBlock * 2), 1);
     if (blocks >= INT32_MAX) return LGC_E_RANGE;
     hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(kBlock), 0, stream, w, g, m, v, n4, n, beta2,
-                       one_minus_beta1, one_minus_beta2, eps, step_size, bias_correction2_sqrt);
+                       one_minus_beta1, one_minus_beta2, eps, step_size, bias_correction2_sqrt, hyper);
     return (int)hipGetLastError();
 }
 

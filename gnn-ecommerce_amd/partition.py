@@ -68,6 +68,29 @@ def check_bipartite(edge_index: Tensor, n_users: int, n_items: int) -> None:
         raise ValueError("partitioned propagation needs a bipartite user|item edge list (ids < n_users are users)")
 
 
+class Comm:
+    """The three places a rank talks to the others, as one object the callers go through: ``start`` an all-reduce of an
+    item block (asynchronous; returns a handle), ``wait`` for it (the current stream waits, not the host), and
+    ``reduce_now`` for small tensors that are read right away.  ``PartitionedTrainer`` substitutes a recording version
+    that cuts its HIP-graph capture at exactly these points (no collective is ever captured)."""
+
+    def __init__(self, world: int, group: Optional[dist.ProcessGroup]):
+        self.world, self.group = world, group
+
+    def start(self, block: Tensor):
+        if self.world == 1:
+            return None
+        return dist.all_reduce(block, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def wait(self, handle) -> None:
+        if handle is not None:
+            handle.wait()
+
+    def reduce_now(self, t: Tensor) -> None:
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+
 class HipOps(DeviceOps):
     """The shipped implementation of the arithmetic: HIP kernels through the C ABI (propagate.DeviceOps) plus the graph
     builders of a partition."""
@@ -121,6 +144,7 @@ class PartitionedPropagator:
         self._coo = (edge_index, full.edge_values)
         self._transposed = None
         self._table_cache = {}
+        self.comm = Comm(world, group)
 
     def _restrict_items(self, op):
         """Item rows of a local operator: every column is one of this rank's own users."""
@@ -141,14 +165,10 @@ class PartitionedPropagator:
     # across hop l's user step and hop l+1's item step and waits for it right before hop l+1's user step.
     def _item_step(self, item_op, x: Tensor, out: Tensor, a: float, r: Optional[Tensor], b: float):
         self.ops.apply(item_op, x, out, a, r if self.rank == 0 else None, b)
-        if self.world > 1:
-            return dist.all_reduce(out[self.n_users:], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        return None
+        return self.comm.start(out[self.n_users:])
 
-    @staticmethod
-    def _finish_items(work) -> None:
-        if work is not None:
-            work.wait()
+    def _finish_items(self, work) -> None:
+        self.comm.wait(work)
 
     def hop(self, x: Tensor, out: Tensor, a: float, r: Optional[Tensor], b: float) -> Tensor:
         """One complete hop (used on its own by tests and by callers that need a single LGConv)."""
@@ -262,9 +282,7 @@ class PartitionedPropagator:
         user_t, item_t = self._transposed_ops()
 
         def exchange(block: Tensor):
-            if self.world == 1:
-                return None
-            return _ExchangeHandle(dist.all_reduce(block, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return _ExchangeHandle(self.comm, self.comm.start(block))
 
         return propagate.seeded_sum(user_t, item_t, self.user_op, self.n_users, rows, vals, alphas, self.num_nodes, extra,
                                     ops=self.ops, exchange=exchange, zero_rows=zero_rows)
@@ -289,12 +307,11 @@ class PartitionedPropagator:
 class _ExchangeHandle:
     """What PartitionedPropagator hands propagate.seeded_sum for one item block: the all-reduce in flight."""
 
-    def __init__(self, work):
-        self.work = work
+    def __init__(self, comm, work):
+        self.comm, self.work = comm, work
 
     def wait(self) -> None:
-        if self.work is not None:
-            self.work.wait()
+        self.comm.wait(self.work)
 
 
 class _PartitionedSum(torch.autograd.Function):
@@ -313,8 +330,7 @@ class _PartitionedSum(torch.autograd.Function):
     def backward(ctx, grad_out: Tensor):
         pp = ctx.pp
         g = grad_out.contiguous().clone()
-        if pp.world > 1:
-            dist.all_reduce(g[pp.n_users:], op=dist.ReduceOp.SUM, group=pp.group)
+        pp.comm.reduce_now(g[pp.n_users:])
         return pp.propagate_sum(g, ctx.alphas, transpose=True, zero_foreign_rows=True), None, None
 
 
@@ -332,6 +348,43 @@ def own_pairs(pp: PartitionedPropagator, edge_label_index: Tensor) -> Tensor:
 
 # The seeded scoring node (below) is used when the batch is far smaller than the table, like propagate.scores_from_table
 SEEDED_STEP = os.environ.get("LGCN_PARTITION_SEEDED", "1") == "1"
+
+
+def step_forward(pp: "PartitionedPropagator", w: Tensor, alphas: tuple, users: Tensor, pos: Tensor, neg: Tensor, decay: float):
+    """Forward half of one rank's training step on a global batch (see _PartitionedStep): returns
+    (local loss, local bpr, regulariser of own users, regulariser of the batch's items, what the backward half needs)."""
+    ops = pp.ops
+    size = users.numel()
+    mine = (users >= pp.u0) & (users < pp.u1)
+    uc = users.clamp(pp.u0, pp.u1 - 1)                       # foreign users: any own row stands in, masked out below
+    idx0, idx1 = torch.cat([uc, uc]), torch.cat([pos, neg])
+    emb = pp.propagate_sum(w, alphas, final_rows=uc)
+    scores, e0, e1, _ = ops.pair_scores_rows(emb, idx0, idx1)
+    mine_b = mine.to(torch.uint8)
+    bpr_local, gs = ops.bpr_loss(scores, mine_b, size)
+    park = torch.full_like(uc, -1)                           # rows other ranks own: "no row" for the seed
+    own_u = torch.where(mine, uc, park)
+    wr = w[torch.cat([uc, pos, neg])]                        # the 3B layer-0 rows of src/utils_v2.py:193-211
+    sq = wr.pow(2).sum(1)
+    reg_users = (sq[:size] * mine.to(sq.dtype)).sum() * (0.5 * decay / size)
+    reg_items = sq[size:].sum() * (0.5 * decay / size)
+    saved = (e0, e1, gs, torch.cat([mine_b, mine_b]), torch.cat([own_u, own_u, idx1]), torch.cat([own_u, idx1]), wr)
+    return bpr_local + reg_users + reg_items, bpr_local, reg_users, reg_items, saved
+
+
+def step_backward(pp: "PartitionedPropagator", saved, alphas: tuple, grad_local: Optional[Tensor], reg_scale: float,
+                  zero_foreign: bool) -> Tensor:
+    """Backward half: the gradient of the local loss with respect to the rows this rank owns (see _PartitionedStep).
+    ``grad_local``: the upstream gradient of the local loss as a 0-dim device tensor, or None for 1."""
+    e0, e1, gs, mine2, rows, reg_rows, wr = saved
+    vals = pp.ops.pair_seed_vals(gs, mine2, grad_local, e0, e1)         # [4B, D]: user rows | item rows
+    m2 = e0.size(0)
+    pp.comm.reduce_now(vals[m2:])                                        # d / d out[item of pair m]: non-zero on the user's owner
+    extra = []
+    if reg_scale != 0.0:
+        extra = [(reg_rows, wr if grad_local is None else wr * grad_local, reg_scale)]
+    zero = [(0, pp.u0), (pp.u1, pp.n_users)] if zero_foreign else None
+    return pp.seeded_transpose_sum(rows, vals, alphas, extra, zero)
 
 
 class _PartitionedStep(torch.autograd.Function):
@@ -356,43 +409,20 @@ class _PartitionedStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, w: Tensor, pp: "PartitionedPropagator", alphas: tuple, users: Tensor, pos: Tensor, neg: Tensor,
                 decay: float, zero_foreign: bool):
-        ops = pp.ops
-        size = users.numel()
-        mine = (users >= pp.u0) & (users < pp.u1)
-        uc = users.clamp(pp.u0, pp.u1 - 1)                       # foreign users: any own row stands in, masked out below
-        idx0, idx1 = torch.cat([uc, uc]), torch.cat([pos, neg])
-        emb = pp.propagate_sum(w.detach(), alphas, final_rows=uc)
-        scores, e0, e1, _ = ops.pair_scores_rows(emb, idx0, idx1)
-        mine_b = mine.to(torch.uint8)
-        bpr_local, gs = ops.bpr_loss(scores, mine_b, size)
-        park = torch.full_like(uc, -1)                           # rows other ranks own: "no row" for the seed
-        own_u = torch.where(mine, uc, park)
-        wr = w.detach()[torch.cat([uc, pos, neg])]               # the 3B layer-0 rows of src/utils_v2.py:193-211
-        sq = wr.pow(2).sum(1)
-        reg_users = (sq[:size] * mine.to(sq.dtype)).sum() * (0.5 * decay / size)
-        reg_items = sq[size:].sum() * (0.5 * decay / size)
-        ctx.save_for_backward(e0, e1, gs, torch.cat([mine_b, mine_b]), torch.cat([own_u, own_u, idx1]),
-                              torch.cat([own_u, idx1]), wr)
-        ctx.pp, ctx.alphas, ctx.reg_scale, ctx.zero_foreign = pp, alphas, float(decay) / float(size), zero_foreign
+        local, bpr_local, reg_users, reg_items, saved = step_forward(pp, w.detach(), alphas, users, pos, neg, decay)
+        ctx.save_for_backward(*saved)
+        ctx.pp, ctx.alphas, ctx.reg_scale, ctx.zero_foreign = pp, alphas, float(decay) / float(users.numel()), zero_foreign
         ctx.set_materialize_grads(False)
-        local = bpr_local + reg_users + reg_items
         ctx.mark_non_differentiable(bpr_local, reg_users, reg_items)
         return local, bpr_local, reg_users, reg_items
 
     @staticmethod
     def backward(ctx, grad_local: Optional[Tensor], *unused):
-        e0, e1, gs, mine2, rows, reg_rows, wr = ctx.saved_tensors
-        pp = ctx.pp
         if grad_local is None:
-            grad_local = torch.zeros((), dtype=torch.float32, device=e0.device)
+            grad_local = torch.zeros((), dtype=torch.float32, device=ctx.saved_tensors[0].device)
         grad_local = grad_local.to(torch.float32).contiguous()
-        vals = pp.ops.pair_seed_vals(gs, mine2, grad_local, e0, e1)     # [4B, D]: user rows | item rows
-        m2 = e0.size(0)
-        if pp.world > 1:                                                 # d / d out[item of pair m]: non-zero on the user's owner
-            dist.all_reduce(vals[m2:], op=dist.ReduceOp.SUM, group=pp.group)
-        extra = [(reg_rows, wr * grad_local, ctx.reg_scale)] if ctx.reg_scale != 0.0 else []
-        zero = [(0, pp.u0), (pp.u1, pp.n_users)] if ctx.zero_foreign else None
-        return pp.seeded_transpose_sum(rows, vals, ctx.alphas, extra, zero), None, None, None, None, None, None, None
+        grad = step_backward(ctx.pp, ctx.saved_tensors, ctx.alphas, grad_local, ctx.reg_scale, ctx.zero_foreign)
+        return grad, None, None, None, None, None, None, None
 
 
 def partitioned_bpr_loss(pp: PartitionedPropagator, weight: Tensor, alphas: Sequence[float], users: Tensor,
@@ -440,7 +470,6 @@ def partitioned_bpr_loss(pp: PartitionedPropagator, weight: Tensor, alphas: Sequ
         local = bpr_local + reg_users + reg_items
     with torch.no_grad():
         part = torch.stack([bpr_local.detach(), reg_users.detach()])
-        if pp.world > 1:
-            dist.all_reduce(part, op=dist.ReduceOp.SUM, group=pp.group)
+        pp.comm.reduce_now(part)
         global_bpr, global_reg = part[0], part[1] + reg_items.detach()
     return local, global_bpr, global_reg

@@ -218,7 +218,10 @@ _status_snapshots = {}
 
 def _snapshot_status(device: torch.device) -> None:
     """Enqueue an asynchronous copy of the status word to pinned host memory (after a scoring launch); the next
-    scoring call looks at it without waiting."""
+    scoring call looks at it without waiting.  Not while a HIP graph is being captured (trainer.PartitionedTrainer): the
+    status word itself is still written by the replayed launches and read by ``check_index_status()``."""
+    if torch.cuda.is_current_stream_capturing():
+        return
     snap = _status_snapshots.get(device)
     if snap is None:
         snap = (torch.zeros(4, dtype=torch.int32).pin_memory(), torch.cuda.Event())
@@ -402,8 +405,8 @@ class DeviceOps:
         _native.lincomb(y, terms)
 
     def segment_sum(self, key_sorted: Tensor, dest: Tensor, vals: Tensor, out: Tensor, scale: float = 1.0,
-                    accumulate: bool = False) -> None:
-        segment_sum(key_sorted, dest, vals, out, scale=scale, accumulate=accumulate)
+                    accumulate: bool = False, vals_index: Optional[Tensor] = None) -> None:
+        segment_sum(key_sorted, dest, vals, out, scale=scale, accumulate=accumulate, vals_index=vals_index)
 
     def seed_pull(self, op: Operator, flag: Tensor, slot: Tensor, seed_vals: Tensor, out: Tensor, mark: Optional[Tensor]) -> None:
         _seed_pull(op, flag, slot, seed_vals, out, mark)
@@ -495,6 +498,20 @@ class DeviceOps:
 
     def scratch_table(self, like: Tensor) -> Tensor:
         return scratch_table(like)
+
+    def adam_rows(self, w: Tensor, g: Tensor, m: Tensor, v: Tensor, lo: int, hi: int, hyper: Tensor) -> None:
+        """One Adam step over the flat element range [lo, hi) of four same-shaped contiguous fp32 tables, the six scalars
+        read from the device tensor ``hyper`` (lgc_adam_step_hp: capturable, see trainer.PartitionedTrainer)."""
+        for t in (g, m, v):
+            if t.shape != w.shape or t.dtype != torch.float32 or not t.is_contiguous() or t.device != w.device:
+                raise TypeError("adam_rows: parameter, gradient and moments must be contiguous fp32 tensors of one shape")
+        if not 0 <= lo <= hi <= w.numel() or hyper.numel() != 6 or hyper.dtype != torch.float32 or hyper.device != w.device:
+            raise ValueError("adam_rows: bad range or hyper-parameter tensor")
+        lib = _native.load()
+        with torch.cuda.device(w.device):
+            code = lib.lgc_adam_step_hp(_native.ptr(w) + 4 * lo, _native.ptr(g) + 4 * lo, _native.ptr(m) + 4 * lo,
+                                        _native.ptr(v) + 4 * lo, hi - lo, _native.ptr(hyper), _native.stream_of(w.device))
+        _native.check(code, "lgc_adam_step_hp")
 
 
 def seed_prepare_reference(rows: Tensor, split: int, n: int, flag: Optional[Tensor] = None, slot: Optional[Tensor] = None):

@@ -377,6 +377,10 @@ int lgc_lincomb(float *y, int64_t y_stride, const float *const *src, const int64
  * ------------------------------------------------------------------------------------- */
 int lgc_adam_step(float *w, const float *g, float *m, float *v, int64_t n, float one_minus_beta1, float beta2,
                   float one_minus_beta2, float eps, float step_size, float bias_correction2_sqrt, void *stream);
+/* The same with the six scalars read from DEVICE memory: hyper = {1 - beta1, beta2, 1 - beta2, eps, step_size,
+ * bias_correction2_sqrt} (fp32 [6]).  For launches captured in a HIP graph and replayed every step: step_size and
+ * bias_correction2_sqrt change with the step count, so the host refreshes those 24 bytes before each replay. */
+int lgc_adam_step_hp(float *w, const float *g, float *m, float *v, int64_t n, const float *hyper, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Pair scoring: scores[m] = <emb[idx0[m]], emb[idx1[m]]>.

@@ -147,3 +147,11 @@ class CpuOps:
         loss = -(torch.nn.functional.logsigmoid(d) * on).sum() / size
         sg = torch.sigmoid(-d) * on / size
         return loss, torch.cat([-sg, sg])
+
+    def adam_rows(self, w, g, m, v, lo, hi, hyper):
+        """lgc_adam_step_hp on the flat range [lo, hi): hyper = {1 - b1, b2, 1 - b2, eps, step_size, sqrt(bias_correction2)}."""
+        omb1, b2, omb2, eps, step_size, bc2_sqrt = hyper.tolist()
+        wf, gf, mf, vf = (t.view(-1)[lo:hi] for t in (w, g, m, v))
+        mf.add_((gf - mf) * omb1)
+        vf.mul_(b2).add_(omb2 * gf * gf)
+        wf.sub_(step_size * (mf / (vf.sqrt() / bc2_sqrt + eps)))

@@ -1176,7 +1176,7 @@ def test_routed_regulariser_takes_every_index_form_upstream_takes(device, monkey
 def test_adam_over_row_ranges_and_foreign_state(device, dim):
     """optim.Adam(row_ranges=...): the rows a rank of a partitioned run owns (two ranges; odd starts give 8-byte aligned
     slices at D = 90, 4-byte at D = 7) get torch.optim.Adam's update, every other row is left alone.  ADVICE r3 (low):
-    moments on another device or of another shape, a strided gradient and a `step` that lives on the device are handled
+    moments on another device or of another shape and a `step` that lives on the device are handled
     before any pointer reaches the kernel."""
     from gnn_ecommerce_amd.optim import Adam as HipAdam
     gen = torch.Generator().manual_seed(5)
@@ -1206,9 +1206,7 @@ def test_adam_over_row_ranges_and_foreign_state(device, dim):
         with pytest.raises(RuntimeError):
             oa.step()
     oa.state[pa]["exp_avg"] = good
-    pa.grad = torch.zeros(rows - 1, dim, device=device)
-    with pytest.raises(RuntimeError):
-        oa.step()
+    oa.step()                                          # (torch itself refuses a gradient of another shape or device)
 
 
 @pytest.mark.parametrize("m", [1, 5, 777, 4096, 8192, 9000])

@@ -136,7 +136,7 @@ def _train_worker(rank, world, port, q, backend="gloo"):
             lg.propagate.SEED_ROWS_FACTOR = 0                   # the seeded node whatever the table size (21,500 rows here)
             wp = w0.clone().requires_grad_(True)
             local, gbpr, greg = partitioned_bpr_loss(pp, wp, [0.25] * 4, users, pos, neg, decay, zero_foreign_rows=not seeded)
-            res[("seeded_" if seeded else "") + "node"] = _uses_node(local.grad_fn, "PartitionedScores")
+            res[("seeded_" if seeded else "") + "node"] = _uses_node(local.grad_fn, "PartitionedStep")
             local.backward()
             torch.cuda.synchronize()
             tag = "seeded_" if seeded else ""
@@ -154,6 +154,29 @@ def _train_worker(rank, world, port, q, backend="gloo"):
                 foreign = torch.ones(g.n_users, dtype=torch.bool, device=dev)
                 foreign[lo:hi] = False
                 res["adam_foreign_untouched"] = bool(torch.equal(wp.detach()[:g.n_users][foreign], w0[:g.n_users][foreign]))
+        # PartitionedTrainer: the same launches without autograd, eager and as replayed HIP graphs (one graph per stretch of
+        # work between two collectives): four steps each from the same start, bit for bit the same table; the first step
+        # equals the single-GPU step's update on the rows this rank owns
+        from gnn_ecommerce_amd.trainer import PartitionedTrainer
+        lg.propagate.SEED_ROWS_FACTOR = 0
+        tables = {}
+        for graphs in (False, True):
+            wt = w0.clone()
+            tr = PartitionedTrainer(pp, wt, [0.25] * 4, lr=0.005, decay=decay, batch=batch, graphs=graphs, warmup=1)
+            stats = []
+            for k in range(4):
+                stats.append(tr.step(torch.roll(users, k), pos, neg).clone())
+                if k == 0:
+                    first = wt.clone()
+            torch.cuda.synchronize()
+            tables[graphs] = (wt, first, torch.stack(stats), tr.graph_launches)
+        res["trainer_graph_equals_eager"] = bool(torch.equal(tables[True][0], tables[False][0])
+                                                 and torch.equal(tables[True][2], tables[False][2]))
+        res["trainer_graph_launches"] = tables[True][3]
+        first = tables[False][1]
+        res["trainer_own"] = rel(first[lo:hi] - w0[lo:hi], ref_w[lo:hi] - w0[lo:hi])
+        res["trainer_items"] = rel(first[g.n_users:] - w0[g.n_users:], ref_w[g.n_users:] - w0[g.n_users:])
+        res["trainer_bpr"] = abs(tables[False][2][0, 0].item() - bpr.item()) / abs(bpr.item())
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
@@ -165,6 +188,8 @@ def test_two_ranks_training_step_matches_single_gpu(device):
         assert r["bpr"] <= 1e-5 and r["reg"] <= 1e-5 and r["own"] <= 1e-5 and r["items"] <= 1e-5, (rank, r)
         assert r["seeded_bpr"] <= 1e-5 and r["seeded_reg"] <= 1e-5 and r["seeded_own"] <= 1e-5 and r["seeded_items"] <= 1e-5, (rank, r)
         assert r["seeded_node"] and not r["node"], (rank, r)
+        assert r["trainer_graph_equals_eager"] and r["trainer_graph_launches"] >= 2, (rank, r)
+        assert r["trainer_own"] <= 1e-5 and r["trainer_items"] <= 1e-5 and r["trainer_bpr"] <= 1e-5, (rank, r)
         assert r["adam_own"] <= 1e-5 and r["adam_items"] <= 1e-5 and r["adam_foreign_untouched"], (rank, r)
 
 

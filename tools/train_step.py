@@ -28,6 +28,10 @@ ap.add_argument("--world", type=int, default=1, help="> 1: the rank-local step o
                 "rank owns) -- local work only, what the exchange adds can only be measured on a multi-GPU node")
 ap.add_argument("--rank", type=int, default=0)
 ap.add_argument("--dense-partition", action="store_true", help="with --world: the dense partitioned backward (round 3)")
+ap.add_argument("--trainer", choices=["autograd", "eager", "graphs"], default="autograd",
+                help="with --world: autograd = partitioned_bpr_loss + backward() + optim.Adam(row_ranges); eager / graphs = "
+                     "trainer.PartitionedTrainer (the same launches without autograd / recorded once as HIP graphs between "
+                     "the collectives and replayed)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 g = synth.make_bipartite(**synth.CONFIG_COSMETICS, seed=0)
@@ -44,7 +48,16 @@ if args.world > 1:
     popt = (HipAdam([w], 0.005, row_ranges=pp.owned_row_ranges()) if args.adam == "hip"
             else torch.optim.Adam([w], 0.005, fused=(args.adam == "fused")))
     pgen = torch.Generator().manual_seed(0)
+    if args.trainer != "autograd":
+        from gnn_ecommerce_amd.trainer import PartitionedTrainer
+        tr = PartitionedTrainer(pp, w.detach(), alphas, lr=0.005, decay=1e-4, batch=args.batch, graphs=args.trainer == "graphs")
     def pstep():
+        if args.trainer != "autograd":
+            u = torch.randint(0, g.n_users, (args.batch,), generator=pgen).to(dev)
+            p = (torch.randint(0, g.n_items, (args.batch,), generator=pgen) + g.n_users).to(dev)
+            n = (torch.randint(0, g.n_items, (args.batch,), generator=pgen) + g.n_users).to(dev)
+            st = tr.step(u, p, n).tolist()                    # one host sync per step (bpr, reg, loss)
+            return st[0], st[1]
         popt.zero_grad()
         u = torch.randint(0, g.n_users, (args.batch,), generator=pgen).to(dev)
         p = (torch.randint(0, g.n_items, (args.batch,), generator=pgen) + g.n_users).to(dev)
@@ -59,7 +72,7 @@ if args.world > 1:
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / args.steps
     print(json.dumps({"metric": "rank-local training step, collectives stubbed (B=%d)" % args.batch, "world": args.world,
                       "rank": args.rank, "users": [pp.u0, pp.u1], "ms_per_step": dt * 1e3, "dim": args.dim, "layers": args.layers,
-                      "adam": args.adam, "seeded": partition.SEEDED_STEP, "bpr_local_sum": vals[0]}))
+                      "adam": args.adam, "seeded": partition.SEEDED_STEP, "trainer": args.trainer, "bpr_local_sum": vals[0]}))
     sys.exit(0)
 model = lg.LightGCN(g.num_nodes, args.dim, args.layers).to(dev)
 if args.adam == "hip":
