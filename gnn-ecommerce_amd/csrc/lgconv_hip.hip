@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
+#include <chrono>
 #include <new>
 #include <thread>
 #include <vector>
@@ -2032,6 +2033,14 @@ void parallel_for(int64_t n, F &&f) {
 int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin, int32_t row_end,
                      int32_t col_lo, int32_t col_hi, const lgc_sweep_cfg &cfg) {
     const int NB = cfg.n_bands, WPBR = cfg.waves_per_band_round, CAP = cfg.row_cap;
+    const bool timing = getenv("LGCN_PLAN_TIMING") != nullptr && atoi(getenv("LGCN_PLAN_TIMING")) != 0;
+    auto clock0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[plan]   %-28s %.3f s\n", what, std::chrono::duration<double>(now - clock0).count());
+        clock0 = now;
+    };
     const int GROUPS = cfg.groups == 2 ? 2 : 4;          // entries per step = rows a wavefront gathers per instruction
     const int SLAB = 64 * GROUPS;                        // dwords per 32-step slab: 1 KiB (4 groups) or 512 B (2)
     const int64_t e0 = rowptr[row_begin], e1 = rowptr[row_end];
@@ -2054,6 +2063,7 @@ int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry 
             while (b < NB && run * NB >= ne * b && ne > 0) bound[b++] = col_lo + c + 1;
         }
     }
+    lap("A bands (histogram)");
     // B. every row sorted by column (stable: equal columns keep edge order); run length of each (row, band)
     std::vector<lgc_entry> sorted((size_t)ne);
     std::vector<int32_t> run_len((size_t)n_rows * NB, 0);
@@ -2072,6 +2082,7 @@ int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry 
             }
         }
     });
+    lap("B rows sorted by column");
     // piece length cap: the configured one, raised in steps of 16 while a longer cap saves a whole round
     auto rounds_for = [&](int64_t pcap) {
         std::vector<int64_t> per_band((size_t)NB, 0);
@@ -2106,6 +2117,7 @@ int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry 
         mr.slot_end = (int32_t)pieces.size();
     }
     const int64_t n_pieces = (int64_t)pieces.size();
+    lap("pieces");
     // C. pieces -> waves, band by band: heaviest first, dealt out in serpentine order (equal piece counts, close loads)
     std::vector<std::vector<int32_t>> by_band((size_t)NB);
     for (int64_t i = 0; i < n_pieces; ++i) by_band[(size_t)pieces[(size_t)i].band].push_back((int32_t)i);
@@ -2135,6 +2147,7 @@ int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry 
     }
     for (auto &wp : wave_pieces)
         if ((int)wp.size() > CAP) return LGC_E_INVAL;   // cannot happen: ceil(n / U) <= CAP
+    lap("C pieces -> waves");
     // D. per wave: merged column-sorted list -> conflict-free steps of 4 -> slabs of 32 steps
     const uint32_t PAD_X = 0x00FFFFFFu | ((uint32_t)CAP << 24);    // out-of-range column, dummy accumulator row
     std::vector<std::vector<uint32_t>> wave_slabs((size_t)n_waves);
@@ -2197,6 +2210,7 @@ int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry 
             wave_pad[(size_t)w] = pad;
         }
     });
+    lap("D steps and slabs per wave");
     pl.wave_slab_ptr.assign((size_t)n_waves + 1, 0);
     int64_t total = 0, n_steps_total = 0, n_pad = 0;
     for (int64_t w = 0; w < n_waves; ++w) {
@@ -2213,6 +2227,7 @@ int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry 
             std::copy(wave_slabs[(size_t)w].begin(), wave_slabs[(size_t)w].end(),
                       pl.slabs.begin() + (size_t)pl.wave_slab_ptr[(size_t)w] * SLAB);
     });
+    lap("slab concatenation");
     pl.dims.n_bands = NB;
     pl.dims.rounds = rounds;
     pl.dims.row_cap = CAP;

@@ -57,6 +57,7 @@ SWEEP_CFG = dict(n_bands=int(os.environ.get("LGCN_SWEEP_BANDS", "8")), waves_per
                  # their band downwards, starting on the rows the previous round left in the Infinity Cache (-2 us)
                  round_order=int(os.environ.get("LGCN_SWEEP_ROUND_ORDER", "2")))
 SWEEP_WIDE = os.environ.get("LGCN_SWEEP_WIDE", "1") == "1"
+PLAN_TIMING = os.environ.get("LGCN_PLAN_TIMING", "0") == "1"     # print where PropGraph.prepare spends its time
 # tables of 68..96 columns: a row takes two DPP rows, LDS rows are 96 floats -> 51 accumulators per wavefront
 SWEEP_CFG_WIDE = dict(SWEEP_CFG, row_cap=int(os.environ.get("LGCN_SWEEP_ROW_CAP_WIDE", "51")), groups=2)
 
@@ -211,16 +212,21 @@ def sweep_plan_host(rowptr: Tensor, entries: Tensor, row_begin: int, row_end: in
     """Run the host planner (lgc_sweep_plan_*) on rows [row_begin, row_end) of a CSR given as tensors on any device;
     returns (dims, CPU arrays).  Host-only code: callable without a GPU (the CPU tests decode the plan)."""
     import ctypes
+    import time
     lib = _native.load()
     cfg = dict(SWEEP_CFG, **(cfg or {}))
+    t0 = time.perf_counter()
     rp = rowptr[row_begin:row_end + 1].to(torch.int64)
     e0, e1 = int(rp[0]), int(rp[-1])
     rp_host = (rp - e0).to(torch.int32).cpu().contiguous()
     ent_host = entries[e0:e1].cpu().contiguous()
+    t1 = time.perf_counter()
     c_cfg = _native.SweepCfg(**cfg)
     code = ctypes.c_int(0)
     handle = lib.lgc_sweep_plan_create(rp_host.data_ptr(), ent_host.data_ptr() if e1 > e0 else None, 0,
                                        row_end - row_begin, col_lo, col_hi, ctypes.byref(c_cfg), ctypes.byref(code))
+    if PLAN_TIMING:
+        print(f"[plan] sweep plan: device -> host copy {t1 - t0:.3f} s, host planner {time.perf_counter() - t1:.3f} s", flush=True)
     if not handle:
         _native.check(code.value or -1, "lgc_sweep_plan_create")
     try:
@@ -569,13 +575,22 @@ class PropGraph:
         rows = self.num_nodes if table_rows is None else int(table_rows)
         stride = dim if dim % 32 == 0 else (dim + 31) // 32 * 32            # propagate.scratch_table's row stride
         ops = self.halves(transpose) if self.split is not None else ((self.transpose_op if transpose else self.forward_op),)
+        import time
         for op in ops:
+            t0 = time.perf_counter()
             if op.tiled and dim >= 4:
                 op.tiles
+            if PLAN_TIMING:
+                torch.cuda.synchronize(self.device)
+                print(f"[plan] rows [{op.plan.row_begin}, {op.plan.row_end}): tile classes {time.perf_counter() - t0:.3f} s", flush=True)
+            t0 = time.perf_counter()
             if op.sweep_cols is not None:
                 groups = sweep_choice(lib, dim, rows, stride)
                 if groups:
                     op.sweep_plan(groups)
+            if PLAN_TIMING:
+                torch.cuda.synchronize(self.device)
+                print(f"[plan] rows [{op.plan.row_begin}, {op.plan.row_end}): sweep plan total {time.perf_counter() - t0:.3f} s", flush=True)
         torch.cuda.synchronize(self.device)
         return self
 
