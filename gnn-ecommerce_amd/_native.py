@@ -73,6 +73,14 @@ SIGNATURES = {
                          c_int32, c_void_p]),
     "lgc_spmm_rows": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                               c_void_p, c_int64, c_float, c_float, c_int32, c_void_p]),
+    "lgc_bipartite_split": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "lgc_row_plan_workspace_bytes": (c_size_t, [c_int64]),
+    "lgc_row_plan_count": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "lgc_row_plan_fill": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lgc_tile_classes_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "lgc_tile_classes": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int64, c_void_p, c_size_t, c_void_p,
+                                 c_void_p, c_void_p]),
+    "lgc_tile_pack": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "lgc_build_tiles": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "lgc_spmm_tiles": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int64, c_void_p, c_int64,
                                c_void_p, c_int64, c_void_p, c_int64, c_float, c_float, c_int32, c_void_p]),
@@ -80,6 +88,8 @@ SIGNATURES = {
                                          POINTER(c_int)]),
     "lgc_sweep_plan_dims": (c_int, [c_void_p, POINTER(SweepDims)]),
     "lgc_sweep_plan_export": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lgc_sweep_plan_upload": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lgc_sweep_plan_export_multi": (c_int, [c_void_p, c_void_p]),
     "lgc_sweep_plan_free": (None, [c_void_p]),
     "lgc_sweep_ok": (c_int, [c_int32, c_int64, c_int64]),
     "lgc_spmm_sweep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p,

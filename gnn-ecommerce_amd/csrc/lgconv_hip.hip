@@ -1387,6 +1387,139 @@ __global__ void k_seed_mark(const int32_t *__restrict__ rowptr, const lgc_entry 
 }
 
 // ----------------------------------------------------------------------------------------
+// One-time index work of a graph, on the device without torch's index kernels (whose first use in a process loads one
+// code object each, lazily: a cold `graph_build_s` was mostly that): the user|item split of an edge list
+// (lgc_bipartite_split) and the chunk plan of the long rows (lgc_row_plan_*; graph.build_row_plan is the reference).
+// ----------------------------------------------------------------------------------------
+__global__ void k_split_init(long long *__restrict__ out) {
+    out[0] = -1;                       // max over edges of min(src, dst)
+    out[1] = 0x7FFFFFFFFFFFFFFFll;     // min over edges of max(src, dst)
+}
+
+__global__ __launch_bounds__(kBlock) void k_bipartite_split(const int64_t *__restrict__ edge_index, int64_t n_edges,
+                                                           long long *__restrict__ out) {
+    long long lo = -1, hi = 0x7FFFFFFFFFFFFFFFll;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges; e += (int64_t)gridDim.x * blockDim.x) {
+        const long long a = edge_index[e], b = edge_index[n_edges + e];
+        lo = max(lo, min(a, b));
+        hi = min(hi, max(a, b));
+    }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        lo = max(lo, (long long)__shfl_xor(lo, off));
+        hi = min(hi, (long long)__shfl_xor(hi, off));
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        atomicMax(&out[0], lo);
+        atomicMin(&out[1], hi);
+    }
+}
+
+// per row of the range: chunks it is cut into (0 for a row of at most short_max entries), whether it is a multi-chunk
+// row, and its partial-sum slots (= chunks, for a multi-chunk row)
+__global__ void k_row_plan_count(const int32_t *__restrict__ rowptr, int32_t row_begin, int32_t row_end, int32_t short_max,
+                                 int32_t chunk_len, int32_t *__restrict__ nch, int32_t *__restrict__ is_multi,
+                                 int32_t *__restrict__ mnch) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= row_end - row_begin) return;
+    const int32_t deg = rowptr[row_begin + i + 1] - rowptr[row_begin + i];
+    const int32_t c = deg > short_max ? (deg + chunk_len - 1) / chunk_len : 0;
+    nch[i] = c;
+    is_multi[i] = c > 1 ? 1 : 0;
+    mnch[i] = c > 1 ? c : 0;
+}
+
+__global__ void k_row_plan_fill(const int32_t *__restrict__ rowptr, int32_t row_begin, int32_t row_end, int32_t short_max,
+                                int32_t chunk_len, const int32_t *__restrict__ chunk_at, const int32_t *__restrict__ multi_at,
+                                const int32_t *__restrict__ slot_at, lgc_chunk *__restrict__ chunks,
+                                lgc_multi_row *__restrict__ multi) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= row_end - row_begin) return;
+    const int32_t row = row_begin + (int32_t)i;
+    const int32_t start = rowptr[row], deg = rowptr[row + 1] - start;
+    if (deg <= short_max) return;
+    const int32_t n = (deg + chunk_len - 1) / chunk_len, per = (deg + n - 1) / n;     // near-equal split
+    const int32_t c0 = chunk_at[i];
+    for (int32_t j = 0; j < n; ++j) {
+        lgc_chunk ch;
+        ch.row = row;
+        ch.begin = start + j * per;
+        ch.end = min(ch.begin + per, start + deg);
+        ch.slot = n > 1 ? slot_at[i] + j : -1;
+        chunks[c0 + j] = ch;
+    }
+    if (n > 1) multi[multi_at[i]] = lgc_multi_row{row, slot_at[i], slot_at[i] + n, 0};
+}
+
+// ----------------------------------------------------------------------------------------
+// Tile classes of the short rows (lgc_tile_classes / lgc_tile_pack): the processing order of lgc_spmm_tiles
+// ----------------------------------------------------------------------------------------
+// What graph.plan_tile_classes computes with ~25 torch launches (bincount, scatter_reduce, three argsorts, gathers ...),
+// as four launches of this library: a process that has never sorted with torch pays 0.3 s for the first use of those
+// kernels alone (their code objects are loaded lazily), which is what a cold `plan_build_s` mostly consisted of.
+//   key of a row  = (class << 58) | (popularity of its least-gathered column << 31) | that column   (cold order)
+//                   class 0 / 1 / 2 = at most 8 / 16 / 32 entries (capped by max_len), 3 = not a tiled row
+//   one stable radix sort of (key, row) puts every class in its processing order, ties in row order.
+__global__ void k_tile_pop(const int32_t *__restrict__ rowptr, const lgc_entry *__restrict__ entries, int32_t row_begin,
+                           int32_t row_end, int32_t *__restrict__ pop) {
+    const int64_t k = (int64_t)rowptr[row_begin] + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < rowptr[row_end]) atomicAdd(&pop[entries[k].col], 1);
+}
+
+__global__ void k_tile_keys(const int32_t *__restrict__ rowptr, const lgc_entry *__restrict__ entries, int32_t row_begin,
+                            int32_t row_end, int32_t cap, int32_t cold, const int32_t *__restrict__ pop,
+                            unsigned long long *__restrict__ keys, int32_t *__restrict__ rows,
+                            unsigned long long *__restrict__ class_count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= row_end - row_begin) return;
+    const int32_t row = row_begin + (int32_t)i;
+    const int32_t s = rowptr[row], e = rowptr[row + 1], deg = e - s;
+    const int c8 = min(8, cap), c16 = min(16, cap), c32 = min(32, cap);
+    const unsigned cls = deg <= c8 ? 0u : deg <= c16 ? 1u : deg <= c32 ? 2u : 3u;
+    unsigned long long low = (1ull << 58) - 1;                  // a row without entries sorts last in its class
+    if (cold && cls < 3u) {
+        for (int32_t k = s; k < e; ++k) {
+            const int32_t c = entries[k].col;
+            const unsigned long long v = ((unsigned long long)(unsigned)pop[c] << 31) | (unsigned)c;
+            low = v < low ? v : low;
+        }
+    } else if (!cold) {
+        low = 0;                                                // natural order: every tie, i.e. row order
+    }
+    keys[i] = ((unsigned long long)cls << 58) | low;
+    rows[i] = row;
+    atomicAdd(&class_count[cls], 1ull);
+}
+
+// One thread per tile of a class: its R rows (the class's sorted list, padded with -1), longest first (stable), rank rho
+// goes to slot (rho % 4) * B + rho / 4 -- lane group rho % 4, batch rho / 4 --, meta byte bt = longest row of batch bt.
+__global__ void k_tile_pack(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ sorted_rows, int64_t n_rows,
+                            int32_t R, int64_t n_tiles, int32_t *__restrict__ order, int32_t *__restrict__ meta) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    int32_t row[16], deg[16];
+    for (int s = 0; s < R; ++s) {
+        const int64_t at = t * R + s;
+        row[s] = at < n_rows ? sorted_rows[at] : -1;
+        deg[s] = row[s] >= 0 ? rowptr[row[s] + 1] - rowptr[row[s]] : -1;
+    }
+    for (int a = 1; a < R; ++a) {                                // stable insertion sort, descending by degree
+        const int32_t r = row[a], d = deg[a];
+        int b = a - 1;
+        while (b >= 0 && deg[b] < d) { row[b + 1] = row[b]; deg[b + 1] = deg[b]; --b; }
+        row[b + 1] = r;
+        deg[b + 1] = d;
+    }
+    const int B = R / 4;
+    int32_t m = 0;
+    for (int rho = 0; rho < R; ++rho) {
+        order[t * R + (rho % 4) * B + rho / 4] = row[rho];
+        if (rho % 4 == 0) m |= max(deg[rho], 0) << (8 * (rho / 4));   // ranks 4 bt .. 4 bt + 3: the first is the longest
+    }
+    meta[t] = m;
+}
+
+// ----------------------------------------------------------------------------------------
 // Seed preparation of the sparse backward pass (lgc_seed_prepare): ONE workgroup sorts up to kSeedMax row ids and
 // derives everything the segment sums and the seeded pull need -- what the host code did with ~25 small launches
 // (sort, gathers, compares, index_puts) per training step.
@@ -2016,7 +2149,7 @@ template <class F>
 void parallel_for(int64_t n, F &&f) {
     unsigned nt = std::thread::hardware_concurrency();
     if (const char *e = getenv("LGCN_PLAN_THREADS")) nt = (unsigned)atoi(e);
-    nt = std::max(1u, std::min(nt, 32u));
+    nt = std::max(1u, std::min(nt, 64u));
     if (nt == 1 || n < 64) {
         f(0, n);
         return;
@@ -2027,6 +2160,20 @@ void parallel_for(int64_t n, F &&f) {
         const int64_t lo = t * per, hi = std::min<int64_t>(n, lo + per);
         if (lo < hi) th.emplace_back([&f, lo, hi] { f(lo, hi); });
     }
+    for (auto &t : th) t.join();
+}
+
+// f(i) for i in [0, n), one thread per index (n is small: the bands of a sweep plan)
+template <class F>
+void parallel_each(int64_t n, F &&f) {
+    unsigned nt = std::thread::hardware_concurrency();
+    if (const char *e = getenv("LGCN_PLAN_THREADS")) nt = (unsigned)atoi(e);
+    if (nt <= 1 || n <= 1) {
+        for (int64_t i = 0; i < n; ++i) f(i);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (int64_t i = 0; i < n; ++i) th.emplace_back([&f, i] { f(i); });
     for (auto &t : th) t.join();
 }
 
@@ -2124,7 +2271,8 @@ int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry 
     const int64_t U = (int64_t)rounds * WPBR;           // waves per band
     const int64_t n_waves = U * NB;
     std::vector<std::vector<int32_t>> wave_pieces((size_t)n_waves);
-    for (int b = 0; b < NB; ++b) {
+    // a band's pieces only ever go to that band's wavefronts (w encodes b): the bands are dealt out in parallel
+    parallel_each(NB, [&](int64_t b) {
         auto &v = by_band[(size_t)b];
         std::stable_sort(v.begin(), v.end(), [&](int32_t a, int32_t c) { return pieces[(size_t)a].count > pieces[(size_t)c].count; });
         const bool by_weight = cfg.round_order >= 1;
@@ -2144,7 +2292,7 @@ int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry 
             const int64_t w = ((r * (WPBR / 4) + j / 4) * NB + b) * 4 + (j % 4);
             wave_pieces[(size_t)w].push_back(v[k]);
         }
-    }
+    });
     for (auto &wp : wave_pieces)
         if ((int)wp.size() > CAP) return LGC_E_INVAL;   // cannot happen: ceil(n / U) <= CAP
     lap("C pieces -> waves");
@@ -2221,7 +2369,7 @@ int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry 
     }
     if (total / SLAB >= INT32_MAX) return LGC_E_RANGE;
     pl.wave_slab_ptr[(size_t)n_waves] = (int32_t)(total / SLAB);
-    pl.slabs.resize((size_t)total);
+    pl.slabs.resize((size_t)total);                 // (zero-fill of ~85 MB: ~10 ms; the copies below overwrite all of it)
     parallel_for(n_waves, [&](int64_t wlo, int64_t whi) {
         for (int64_t w = wlo; w < whi; ++w)
             std::copy(wave_slabs[(size_t)w].begin(), wave_slabs[(size_t)w].end(),
@@ -2455,6 +2603,167 @@ int lgc_spmm_rows(const int32_t *rowptr, const lgc_entry *entries, int32_t row_b
     });
 }
 
+int lgc_bipartite_split(const int64_t *edge_index, int64_t n_edges, int64_t *out2, void *stream_) {
+    if (!out2 || n_edges < 0 || (n_edges > 0 && !edge_index)) return LGC_E_INVAL;
+    hipStream_t st = as_stream(stream_);
+    hipLaunchKernelGGL(k_split_init, dim3(1), dim3(1), 0, st, reinterpret_cast<long long *>(out2));
+    if (n_edges > 0)
+        hipLaunchKernelGGL(k_bipartite_split, dim3((unsigned)std::min<int64_t>(ceil_div(n_edges, kBlock), 256 * 16)), dim3(kBlock), 0,
+                           st, edge_index, n_edges, reinterpret_cast<long long *>(out2));
+    return (int)hipGetLastError();
+}
+
+static size_t row_plan_ws(void *base, int64_t n, int32_t **a, int32_t **b, int32_t **c, void **cub, size_t *cub_bytes) {
+    size_t cb = 0;
+    int32_t *nul = nullptr;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, cb, nul, nul, (int)std::max<int64_t>(n, 1), (hipStream_t)0);
+    const uintptr_t p = reinterpret_cast<uintptr_t>(base);
+    const size_t arr = align_up((size_t)(n + 1) * 4, 256);
+    if (a) *a = reinterpret_cast<int32_t *>(p);
+    if (b) *b = reinterpret_cast<int32_t *>(p + arr);
+    if (c) *c = reinterpret_cast<int32_t *>(p + 2 * arr);
+    if (cub) *cub = reinterpret_cast<void *>(p + 3 * arr);
+    if (cub_bytes) *cub_bytes = cb;
+    return 3 * arr + align_up(cb, 256) + 256;
+}
+
+size_t lgc_row_plan_workspace_bytes(int64_t n_rows) {
+    if (n_rows < 0 || n_rows >= INT32_MAX) return 0;
+    return row_plan_ws(nullptr, n_rows, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+// Phase 1: per-row counts and their exclusive prefix sums (one extra element each = the totals), left in the workspace;
+// totals[3] (int32, device) = chunks, multi-chunk rows, slots.  Phase 2 (lgc_row_plan_fill) writes the two lists.
+int lgc_row_plan_count(const int32_t *rowptr, int32_t row_begin, int32_t row_end, int32_t short_max, int32_t chunk_len,
+                       void *workspace, size_t workspace_bytes, int32_t *totals, void *stream_) {
+    if (!rowptr || !totals || row_begin < 0 || row_end < row_begin || short_max < 0 || chunk_len < 1) return LGC_E_INVAL;
+    const int64_t n = (int64_t)row_end - row_begin;
+    hipStream_t st = as_stream(stream_);
+    if (n > 0) {
+        if (!workspace) return LGC_E_INVAL;
+        if (workspace_bytes < lgc_row_plan_workspace_bytes(n)) return LGC_E_WORKSPACE;
+        if (!aligned_to(workspace, 256)) return LGC_E_ALIGN;
+    }
+    hipError_t err = hipMemsetAsync(totals, 0, 3 * sizeof(int32_t), st);
+    if (err != hipSuccess) return (int)err;
+    if (n == 0) return 0;
+    int32_t *a, *b, *c;
+    void *cub;
+    size_t cub_bytes;
+    row_plan_ws(workspace, n, &a, &b, &c, &cub, &cub_bytes);
+    // one extra trailing zero per array, so that the exclusive sum's element n is the total
+    for (int32_t *arr : {a, b, c}) {
+        err = hipMemsetAsync(arr + n, 0, sizeof(int32_t), st);
+        if (err != hipSuccess) return (int)err;
+    }
+    hipLaunchKernelGGL(k_row_plan_count, dim3(ceil_div(n, kBlock)), dim3(kBlock), 0, st, rowptr, row_begin, row_end, short_max,
+                       chunk_len, a, b, c);
+    int k = 0;
+    for (int32_t *arr : {a, b, c}) {
+        err = hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, arr, arr, (int)(n + 1), st);
+        if (err == hipSuccess) err = hipMemcpyAsync(totals + k, arr + n, sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+        if (err != hipSuccess) return (int)err;
+        ++k;
+    }
+    return (int)hipGetLastError();
+}
+
+int lgc_row_plan_fill(const int32_t *rowptr, int32_t row_begin, int32_t row_end, int32_t short_max, int32_t chunk_len,
+                      const void *workspace, lgc_chunk *chunks, lgc_multi_row *multi, void *stream_) {
+    if (!rowptr || row_begin < 0 || row_end < row_begin || short_max < 0 || chunk_len < 1) return LGC_E_INVAL;
+    const int64_t n = (int64_t)row_end - row_begin;
+    if (n == 0) return 0;
+    if (!workspace || !chunks || !multi) return LGC_E_INVAL;
+    int32_t *a, *b, *c;
+    row_plan_ws(const_cast<void *>(workspace), n, &a, &b, &c, nullptr, nullptr);
+    hipLaunchKernelGGL(k_row_plan_fill, dim3(ceil_div(n, kBlock)), dim3(kBlock), 0, as_stream(stream_), rowptr, row_begin, row_end,
+                       short_max, chunk_len, a, b, c, chunks, multi);
+    return (int)hipGetLastError();
+}
+
+static size_t tile_classes_ws(void *base, int64_t n_rows, int64_t table_rows, int32_t **pop, unsigned long long **k_in,
+                              unsigned long long **k_out, int32_t **v_in, void **cub, size_t *cub_bytes) {
+    size_t cb = 0;
+    unsigned long long *nk = nullptr;
+    int32_t *nv = nullptr;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, cb, nk, nk, nv, nv, (int)std::max<int64_t>(n_rows, 1), 0, 60, (hipStream_t)0);
+    const uintptr_t p = reinterpret_cast<uintptr_t>(base);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t at = off; off += align_up(bytes, 256); return p + at; };
+    const uintptr_t a_pop = take((size_t)table_rows * 4), a_ki = take((size_t)n_rows * 8), a_ko = take((size_t)n_rows * 8),
+                    a_vi = take((size_t)n_rows * 4), a_cub = take(cb);
+    if (pop) *pop = reinterpret_cast<int32_t *>(a_pop);
+    if (k_in) *k_in = reinterpret_cast<unsigned long long *>(a_ki);
+    if (k_out) *k_out = reinterpret_cast<unsigned long long *>(a_ko);
+    if (v_in) *v_in = reinterpret_cast<int32_t *>(a_vi);
+    if (cub) *cub = reinterpret_cast<void *>(a_cub);
+    if (cub_bytes) *cub_bytes = cb;
+    return off + 256;
+}
+
+size_t lgc_tile_classes_workspace_bytes(int64_t n_rows, int64_t table_rows) {
+    if (n_rows < 0 || table_rows < 0 || n_rows >= INT32_MAX || table_rows >= INT32_MAX) return 0;
+    return tile_classes_ws(nullptr, n_rows, table_rows, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+int lgc_tile_classes(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin, int32_t row_end, int32_t max_len,
+                     int32_t cold, int64_t table_rows, void *workspace, size_t workspace_bytes, int32_t *sorted_rows,
+                     uint64_t *class_count, void *stream_) {
+    if (!rowptr || !sorted_rows || !class_count || row_begin < 0 || row_end < row_begin || table_rows < row_end || max_len < 0 ||
+        table_rows >= INT32_MAX)
+        return LGC_E_INVAL;
+    const int64_t n = (int64_t)row_end - row_begin;
+    hipStream_t st = as_stream(stream_);
+    if (n > 0) {                                  // every argument is checked before the first call into the runtime
+        if (!workspace) return LGC_E_INVAL;       // (entries may be NULL for rows without a single entry: checked below)
+        if (workspace_bytes < lgc_tile_classes_workspace_bytes(n, table_rows)) return LGC_E_WORKSPACE;
+        if (!aligned_to(workspace, 256)) return LGC_E_ALIGN;
+    }
+    hipError_t err = hipMemsetAsync(class_count, 0, 4 * sizeof(uint64_t), st);
+    if (err != hipSuccess) return (int)err;
+    if (n == 0) return 0;
+    int32_t *pop, *v_in;
+    unsigned long long *k_in, *k_out;
+    void *cub;
+    size_t cub_bytes;
+    tile_classes_ws(workspace, n, table_rows, &pop, &k_in, &k_out, &v_in, &cub, &cub_bytes);
+    const int32_t cap = std::min(max_len, 32);
+    if (cold) {
+        err = hipMemsetAsync(pop, 0, (size_t)table_rows * 4, st);
+        if (err != hipSuccess) return (int)err;
+        // the entry range of the rows is known on the device only: one thread per entry of the whole CSR at most is
+        // wasteful, so the launch is sized by an upper bound the caller's CSR gives for free -- rows hold <= 2^31 entries;
+        // the kernel bounds itself by rowptr[row_end]
+        int32_t ends[2];
+        err = hipMemcpyAsync(&ends[0], rowptr + row_begin, 4, hipMemcpyDeviceToHost, st);
+        if (err == hipSuccess) err = hipMemcpyAsync(&ends[1], rowptr + row_end, 4, hipMemcpyDeviceToHost, st);
+        if (err == hipSuccess) err = hipStreamSynchronize(st);
+        if (err != hipSuccess) return (int)err;
+        const int64_t n_ent = (int64_t)ends[1] - ends[0];
+        if (n_ent > 0 && !entries) return LGC_E_INVAL;
+        if (n_ent > 0)
+            hipLaunchKernelGGL(k_tile_pop, dim3(ceil_div(n_ent, kBlock)), dim3(kBlock), 0, st, rowptr, entries, row_begin, row_end,
+                               pop);
+    }
+    hipLaunchKernelGGL(k_tile_keys, dim3(ceil_div(n, kBlock)), dim3(kBlock), 0, st, rowptr, entries, row_begin, row_end, cap,
+                       cold ? 1 : 0, pop, k_in, v_in, reinterpret_cast<unsigned long long *>(class_count));
+    err = hipcub::DeviceRadixSort::SortPairs(cub, cub_bytes, k_in, k_out, v_in, sorted_rows, (int)n, 0, 60, st);
+    if (err != hipSuccess) return (int)err;
+    return (int)hipGetLastError();
+}
+
+int lgc_tile_pack(const int32_t *rowptr, const int32_t *sorted_rows, int64_t n_rows, int32_t width, int32_t *order, int32_t *meta,
+                  void *stream_) {
+    if (!rowptr || n_rows < 0 || (width != 8 && width != 16 && width != 32)) return LGC_E_INVAL;
+    if (n_rows == 0) return 0;
+    if (!sorted_rows || !order || !meta) return LGC_E_INVAL;
+    const int R = 128 * (width == 32 ? 2 : 1) / width;
+    const int64_t n_tiles = (n_rows + R - 1) / R;
+    hipLaunchKernelGGL(k_tile_pack, dim3(ceil_div(n_tiles, kBlock)), dim3(kBlock), 0, as_stream(stream_), rowptr, sorted_rows, n_rows,
+                       R, n_tiles, order, meta);
+    return (int)hipGetLastError();
+}
+
 int lgc_build_tiles(const int32_t *rowptr, const lgc_entry *entries, const int32_t *order, int64_t n_slots, int32_t width,
                     lgc_entry *slab, void *stream_) {
     if (!rowptr || !order || !slab || n_slots < 0 || (width != 8 && width != 16 && width != 32)) return LGC_E_INVAL;
@@ -2528,6 +2837,27 @@ int lgc_sweep_plan_export(const lgc_sweep_plan *plan, uint32_t *slabs, int32_t *
     std::copy(plan->piece_slot.begin(), plan->piece_slot.end(), piece_slot);
     std::copy(plan->multi.begin(), plan->multi.end(), multi);
     return 0;
+}
+
+int lgc_sweep_plan_export_multi(const lgc_sweep_plan *plan, lgc_multi_row *multi) {
+    if (!plan || !multi) return LGC_E_INVAL;
+    std::copy(plan->multi.begin(), plan->multi.end(), multi);
+    return 0;
+}
+
+int lgc_sweep_plan_upload(const lgc_sweep_plan *plan, uint32_t *slabs, int32_t *wave_slab_ptr, int32_t *wave_npieces,
+                          int32_t *piece_slot, void *stream_) {
+    if (!plan || !slabs || !wave_slab_ptr || !wave_npieces || !piece_slot) return LGC_E_INVAL;
+    hipStream_t st = as_stream(stream_);
+    auto up = [&](void *dst, const void *src, size_t bytes) -> int {
+        return bytes == 0 ? 0 : (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+    };
+    int rc = up(slabs, plan->slabs.data(), plan->slabs.size() * sizeof(uint32_t));
+    if (rc == 0) rc = up(wave_slab_ptr, plan->wave_slab_ptr.data(), plan->wave_slab_ptr.size() * sizeof(int32_t));
+    if (rc == 0) rc = up(wave_npieces, plan->wave_npieces.data(), plan->wave_npieces.size() * sizeof(int32_t));
+    if (rc == 0) rc = up(piece_slot, plan->piece_slot.data(), plan->piece_slot.size() * sizeof(int32_t));
+    if (rc != 0) return rc;
+    return (int)hipStreamSynchronize(st);       // the plan's host arrays may be freed as soon as this returns
 }
 
 void lgc_sweep_plan_free(lgc_sweep_plan *plan) { delete plan; }

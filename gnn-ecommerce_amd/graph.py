@@ -120,6 +120,37 @@ def build_row_plan(rowptr: Tensor, row_begin: int, row_end: int,
 
 
 
+def build_row_plan_device(rowptr: Tensor, row_begin: int, row_end: int, short_max: int = SHORT_MAX,
+                          chunk_len: int = CHUNK_LEN) -> RowPlan:
+    """``build_row_plan`` as three launches + two scans of the library (lgc_row_plan_count / _fill): the same lists without
+    torch's nonzero / cumsum / repeat_interleave kernels (lazy code-object loads on their first use in a process)."""
+    if short_max < 0 or chunk_len < 1:
+        raise ValueError("short_max must be >= 0 and chunk_len >= 1")
+    lib = _native.load()
+    dev = rowptr.device
+    n = row_end - row_begin
+    ws_bytes = lib.lgc_row_plan_workspace_bytes(n)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    totals = torch.empty(3, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        code = lib.lgc_row_plan_count(_native.ptr(rowptr), row_begin, row_end, short_max, chunk_len, _native.ptr(ws), ws_bytes,
+                                      _native.ptr(totals), _native.stream_of(dev))
+    _native.check(code, "lgc_row_plan_count")
+    n_chunks, n_multi, n_slots = totals.tolist()              # the one sync
+    chunks = torch.empty((n_chunks, 4), dtype=torch.int32, device=dev)
+    multi = torch.empty((n_multi, 4), dtype=torch.int32, device=dev)
+    if n_chunks:
+        with torch.cuda.device(dev):
+            code = lib.lgc_row_plan_fill(_native.ptr(rowptr), row_begin, row_end, short_max, chunk_len, _native.ptr(ws),
+                                         _native.ptr(chunks), _native.ptr(multi) if n_multi else _native.ptr(chunks),
+                                         _native.stream_of(dev))
+        _native.check(code, "lgc_row_plan_fill")
+    return RowPlan(row_begin, row_end, short_max, chunks, multi, n_slots)
+
+
+ROW_PLAN_NATIVE = os.environ.get("LGCN_ROW_PLAN_NATIVE", "1") == "1"
+
+
 def tile_geometry(width: int) -> Tuple[int, int]:
     """(rows per tile R, batches of four rows B) of a width class: a tile is 1 KiB of row heads (2 KiB for 32)."""
     if width not in TILE_WIDTHS:
@@ -193,11 +224,53 @@ class TileClass:
         return self.meta.numel()
 
 
+def plan_tile_classes_device(rowptr: Tensor, entries: Tensor, row_begin: int, row_end: int, max_len: int,
+                             mode: str = "cold") -> List[Tuple[int, Tensor, Tensor]]:
+    """``plan_tile_classes`` as four launches of the library (lgc_tile_classes: popularity histogram, row keys, one stable
+    radix sort; lgc_tile_pack per class) -- the same lists, without the two dozen torch index kernels whose first use in a
+    process costs 0.3 s of lazy code-object loading.  One host sync (the three class sizes)."""
+    if mode not in ("cold", "natural"):
+        raise ValueError("tile order must be 'cold' or 'natural'")
+    lib = _native.load()
+    dev = rowptr.device
+    n = row_end - row_begin
+    table_rows = rowptr.numel() - 1
+    ws_bytes = lib.lgc_tile_classes_workspace_bytes(n, table_rows)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    sorted_rows = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    counts = torch.empty(4, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        code = lib.lgc_tile_classes(_native.ptr(rowptr), _native.ptr(entries), row_begin, row_end, int(max_len), int(mode == "cold"),
+                                    table_rows, _native.ptr(ws), ws_bytes, _native.ptr(sorted_rows), _native.ptr(counts),
+                                    _native.stream_of(dev))
+    _native.check(code, "lgc_tile_classes")
+    sizes = counts.tolist()                                   # the one sync
+    out, start = [], 0
+    for width, size in zip(TILE_WIDTHS, sizes[:3]):
+        if size > 0:
+            r_tile, _ = tile_geometry(width)
+            n_tiles = (size + r_tile - 1) // r_tile
+            order = torch.empty(n_tiles * r_tile, dtype=torch.int32, device=dev)
+            meta = torch.empty(n_tiles, dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                code = lib.lgc_tile_pack(_native.ptr(rowptr), sorted_rows.data_ptr() + 4 * start, size, width, _native.ptr(order),
+                                         _native.ptr(meta), _native.stream_of(dev))
+            _native.check(code, "lgc_tile_pack")
+            out.append((width, order, meta))
+        start += size
+    return out
+
+
+TILE_PLAN_NATIVE = os.environ.get("LGCN_TILE_PLAN_NATIVE", "1") == "1"
+
+
 def build_tile_classes(rowptr: Tensor, entries: Tensor, row_begin: int, row_end: int, max_len: int,
                        mode: Optional[str] = None) -> List[TileClass]:
     lib = _native.load()
     classes = []
-    for width, order, meta in plan_tile_classes(rowptr, entries[:, 0], row_begin, row_end, max_len, mode or TILE_ORDER):
+    plan = plan_tile_classes_device(rowptr, entries, row_begin, row_end, max_len, mode or TILE_ORDER) if TILE_PLAN_NATIVE \
+        else plan_tile_classes(rowptr, entries[:, 0], row_begin, row_end, max_len, mode or TILE_ORDER)
+    for width, order, meta in plan:
         slab = torch.empty((order.numel() * width, 2), dtype=torch.int32, device=rowptr.device)
         with torch.cuda.device(rowptr.device):
             code = lib.lgc_build_tiles(_native.ptr(rowptr), _native.ptr(entries), _native.ptr(order), order.numel(), width,
@@ -207,18 +280,17 @@ def build_tile_classes(rowptr: Tensor, entries: Tensor, row_begin: int, row_end:
     return classes
 
 
-def sweep_plan_host(rowptr: Tensor, entries: Tensor, row_begin: int, row_end: int, col_lo: int, col_hi: int,
-                    cfg: Optional[dict] = None) -> Tuple[dict, Dict[str, Tensor]]:
-    """Run the host planner (lgc_sweep_plan_*) on rows [row_begin, row_end) of a CSR given as tensors on any device;
-    returns (dims, CPU arrays).  Host-only code: callable without a GPU (the CPU tests decode the plan)."""
+def _sweep_plan_create(rowptr: Tensor, entries: Tensor, row_begin: int, row_end: int, col_lo: int, col_hi: int,
+                       cfg: Optional[dict]):
+    """Host copies of rows [row_begin, row_end) -> lgc_sweep_plan_create.  Returns (handle, dims)."""
     import ctypes
     import time
     lib = _native.load()
     cfg = dict(SWEEP_CFG, **(cfg or {}))
     t0 = time.perf_counter()
-    rp = rowptr[row_begin:row_end + 1].to(torch.int64)
+    rp = rowptr[row_begin:row_end + 1]
     e0, e1 = int(rp[0]), int(rp[-1])
-    rp_host = (rp - e0).to(torch.int32).cpu().contiguous()
+    rp_host = (rp.cpu() - e0).contiguous()          # relative to the first entry of the slice (kept alive across the call)
     ent_host = entries[e0:e1].cpu().contiguous()
     t1 = time.perf_counter()
     c_cfg = _native.SweepCfg(**cfg)
@@ -229,9 +301,22 @@ def sweep_plan_host(rowptr: Tensor, entries: Tensor, row_begin: int, row_end: in
         print(f"[plan] sweep plan: device -> host copy {t1 - t0:.3f} s, host planner {time.perf_counter() - t1:.3f} s", flush=True)
     if not handle:
         _native.check(code.value or -1, "lgc_sweep_plan_create")
+    d = _native.SweepDims()
     try:
-        d = _native.SweepDims()
         _native.check(lib.lgc_sweep_plan_dims(handle, ctypes.byref(d)), "lgc_sweep_plan_dims")
+    except Exception:
+        lib.lgc_sweep_plan_free(handle)
+        raise
+    return handle, d
+
+
+def sweep_plan_host(rowptr: Tensor, entries: Tensor, row_begin: int, row_end: int, col_lo: int, col_hi: int,
+                    cfg: Optional[dict] = None) -> Tuple[dict, Dict[str, Tensor]]:
+    """Run the host planner (lgc_sweep_plan_*) on rows [row_begin, row_end) of a CSR given as tensors on any device;
+    returns (dims, CPU arrays).  Host-only code: callable without a GPU (the CPU tests decode the plan)."""
+    lib = _native.load()
+    handle, d = _sweep_plan_create(rowptr, entries, row_begin, row_end, col_lo, col_hi, cfg)
+    try:
         dims = {k: getattr(d, k) for k, _ in _native.SweepDims._fields_}
         arrays = {"slabs": torch.empty(max(d.n_slabs, 1) * 64 * d.groups, dtype=torch.int32),
                   "wave_slab_ptr": torch.empty(d.n_waves + 1, dtype=torch.int32),
@@ -248,6 +333,33 @@ def sweep_plan_host(rowptr: Tensor, entries: Tensor, row_begin: int, row_end: in
     return dims, arrays
 
 
+def sweep_plan_device(rowptr: Tensor, entries: Tensor, row_begin: int, row_end: int, col_lo: int, col_hi: int,
+                      cfg: Optional[dict] = None) -> Tuple[dict, Dict[str, Tensor]]:
+    """The same plan with its four big arrays copied straight from the planner's memory into device tensors
+    (lgc_sweep_plan_upload: no intermediate host tensors, ~90 MB less to copy); ``multi`` comes back on the host."""
+    lib = _native.load()
+    dev = rowptr.device
+    handle, d = _sweep_plan_create(rowptr, entries, row_begin, row_end, col_lo, col_hi, cfg)
+    try:
+        dims = {k: getattr(d, k) for k, _ in _native.SweepDims._fields_}
+        i32 = dict(dtype=torch.int32, device=dev)
+        arrays = {"slabs": torch.empty(max(d.n_slabs, 1) * 64 * d.groups, **i32),
+                  "wave_slab_ptr": torch.empty(d.n_waves + 1, **i32),
+                  "wave_npieces": torch.empty(max(d.n_waves, 1), **i32),
+                  "piece_slot": torch.empty(max(d.n_waves * d.row_cap, 1), **i32),
+                  "multi": torch.empty((max(d.n_rows, 1), 4), dtype=torch.int32)}
+        with torch.cuda.device(dev):
+            _native.check(lib.lgc_sweep_plan_upload(handle, *(arrays[k].data_ptr() for k in
+                                                              ("slabs", "wave_slab_ptr", "wave_npieces", "piece_slot")),
+                                                    _native.stream_of(dev)), "lgc_sweep_plan_upload")
+        _native.check(lib.lgc_sweep_plan_export_multi(handle, arrays["multi"].data_ptr()), "lgc_sweep_plan_export_multi")
+    finally:
+        lib.lgc_sweep_plan_free(handle)
+    arrays["multi"] = arrays["multi"][:d.n_rows].contiguous()
+    arrays["multi"][:, 0] += row_begin
+    return dims, arrays
+
+
 class SweepPlan:
     """Device arrays of a band-sweep plan (include/lgconv_hip.h, lgc_sweep_plan_*): built once per operator half on
     the host from a host copy of its rows, uploaded, then applied with lgc_spmm_sweep."""
@@ -255,7 +367,8 @@ class SweepPlan:
     def __init__(self, rowptr: Tensor, entries: Tensor, row_begin: int, row_end: int, col_lo: int, col_hi: int,
                  cfg: Optional[dict] = None):
         dev = rowptr.device
-        self.dims, arrays = sweep_plan_host(rowptr, entries, row_begin, row_end, col_lo, col_hi, cfg)
+        plan = sweep_plan_device if rowptr.is_cuda else sweep_plan_host
+        self.dims, arrays = plan(rowptr, entries, row_begin, row_end, col_lo, col_hi, cfg)
         self.row_begin, self.row_end = row_begin, row_end
         self.slabs, self.wave_slab_ptr = arrays["slabs"].to(dev), arrays["wave_slab_ptr"].to(dev)
         self.wave_npieces, self.piece_slot = arrays["wave_npieces"].to(dev), arrays["piece_slot"].to(dev)
@@ -307,7 +420,8 @@ class Operator:
         use_tiles = USE_TILES if tiles is None else tiles
         if use_tiles and rowptr.is_cuda:
             short_max = min(short_max, TILE_WIDTHS[-1])
-        op = cls(n_rows, rowptr, entries, build_row_plan(rowptr, row_begin, row_end, short_max, chunk_len),
+        plan = build_row_plan_device if (ROW_PLAN_NATIVE and rowptr.is_cuda) else build_row_plan
+        op = cls(n_rows, rowptr, entries, plan(rowptr, row_begin, row_end, short_max, chunk_len),
                  bool(use_tiles and rowptr.is_cuda))
         if sweep_cols is not None and rowptr.is_cuda and USE_SWEEP != "0" and sweep_cols[1] <= 0xFFFFFF:
             # long rows over a table far beyond the caches: the item half of a user|item graph, not its user half
@@ -542,9 +656,13 @@ class PropGraph:
         src/utils_v2.py:146-165 -- or None.  Two reductions over the COO, one host sync per graph."""
         if self.num_edges == 0:
             return None
-        lo = torch.minimum(self._edge_index[0], self._edge_index[1]).max()
-        hi = torch.maximum(self._edge_index[0], self._edge_index[1]).min()
-        lo, hi = int(lo.item()), int(hi.item())
+        out = torch.empty(2, dtype=torch.int64, device=self.device)
+        lib = _native.load()
+        with torch.cuda.device(self.device):
+            code = lib.lgc_bipartite_split(_native.ptr(self._edge_index), self.num_edges, _native.ptr(out),
+                                           _native.stream_of(self.device))
+        _native.check(code, "lgc_bipartite_split")
+        lo, hi = out.tolist()
         return lo + 1 if lo < hi else None
 
     def halves(self, transpose: bool = False) -> Tuple[Operator, Operator]:

@@ -645,7 +645,10 @@ def seeded_sum(user_t, item_t, user_fwd, split: int, rows: Tensor, vals: Tensor,
                 ops.lincomb(mix[split:], [(alphas[l], tables[l - 1][split:]) for l in range(1, k + 1)])
                 ops.apply(user_t, mix, out, a=1.0)
                 wait(pending[k])
-                ops.lincomb(out[split:], [(alphas[l], tables[l][split:]) for l in range(0, k + 1)])
+                if all(a == alphas[0] for a in alphas):     # equal alphas: mix + a x_K is the same chain of adds
+                    ops.lincomb(out[split:], [(1.0, mix[split:]), (alphas[k], tables[k][split:])])
+                else:
+                    ops.lincomb(out[split:], [(alphas[l], tables[l][split:]) for l in range(0, k + 1)])
                 # + alpha_0 g on the seed users (each such row is owned by one lane group: read, add, write)
                 ops.segment_sum(rows_s, dest_user, vals, out, scale=alphas[0], accumulate=True, vals_index=perm)
     return finish(out)

@@ -123,7 +123,7 @@ class PartitionedTrainer:
             rec["inner"].reduce_now(action[1])
             rec["actions"].append(("reduce", action[1]))
         rec["graph"] = torch.cuda.CUDAGraph()
-        rec["graph"].capture_begin(pool=rec["pool"])
+        rec["graph"].capture_begin(pool=rec["pool"], capture_error_mode="thread_local")
         return slot
 
     @staticmethod
@@ -137,6 +137,10 @@ class PartitionedTrainer:
         rec["actions"].append(("graph", rec["graph"]))
 
     def _record(self) -> None:
+        # capture_error_mode "thread_local": the exchange started before a segment may still be running in the
+        # communication backend's own threads (gloo copies through the host; RCCL's watchdog polls events) while the next
+        # segment is being captured -- legal, but under the default "global" mode any runtime call of ANOTHER thread
+        # invalidates the capture.
         from . import propagate
         dev = self.w.device
         inner = self.pp.comm
@@ -149,7 +153,7 @@ class PartitionedTrainer:
         self.pp.comm = _RecordingComm(inner, self)
         try:
             with torch.cuda.stream(stream):
-                rec["graph"].capture_begin(pool=rec["pool"])
+                rec["graph"].capture_begin(pool=rec["pool"], capture_error_mode="thread_local")
                 try:
                     self._body()
                 finally:

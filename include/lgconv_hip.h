@@ -106,6 +106,22 @@ int lgc_build_csr(const int64_t *edge_index, const float *edge_weight,
                   void *workspace, size_t workspace_bytes,
                   int32_t *status, void *stream);
 
+/* The user|item split of an edge list in the layout of src/utils_v2.py:146-165 (ids below n_users are users): out2[0] =
+ * max over edges of min(source, target), out2[1] = min over edges of max(source, target) (int64 [2], device).  The graph is
+ * user|item with split = out2[0] + 1 iff out2[0] < out2[1].  One pass over the COO. */
+int lgc_bipartite_split(const int64_t *edge_index, int64_t n_edges, int64_t *out2, void *stream);
+
+/* The work list of lgc_spmm's long rows, built on the device: every row of [row_begin, row_end) with more than `short_max`
+ * entries is cut into ceil(deg / chunk_len) near-equal chunks, listed in row order; a row with several chunks gets
+ * consecutive partial-sum slots and an lgc_multi_row.  lgc_row_plan_count leaves per-row prefix sums in `workspace`
+ * (>= lgc_row_plan_workspace_bytes(n_rows)) and writes totals[3] = {chunks, multi-chunk rows, slots} (int32, device);
+ * the caller sizes `chunks` and `multi` from them and calls lgc_row_plan_fill with the same arguments and workspace. */
+size_t lgc_row_plan_workspace_bytes(int64_t n_rows);
+int lgc_row_plan_count(const int32_t *rowptr, int32_t row_begin, int32_t row_end, int32_t short_max, int32_t chunk_len,
+                       void *workspace, size_t workspace_bytes, int32_t *totals, void *stream);
+int lgc_row_plan_fill(const int32_t *rowptr, int32_t row_begin, int32_t row_end, int32_t short_max, int32_t chunk_len,
+                      const void *workspace, lgc_chunk *chunks, lgc_multi_row *multi, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Tiled rows: rows with at most 32 entries, listed in a caller-chosen processing order.
  *
@@ -125,6 +141,21 @@ int lgc_build_csr(const int64_t *edge_index, const float *edge_weight,
  */
 int lgc_build_tiles(const int32_t *rowptr, const lgc_entry *entries, const int32_t *order, int64_t n_slots,
                     int32_t width, lgc_entry *slab, void *stream);
+
+/* The processing order itself, on the device (what the host code otherwise derives with two dozen index operations):
+ * lgc_tile_classes sorts the rows of [row_begin, row_end) by (width class, key, row id) -- class 0 / 1 / 2 = at most
+ * min(8 | 16 | 32, max_len) entries (a row goes to the narrowest class that holds it; 0 entries -> class 0), class 3 = every
+ * longer row; key = (popularity of the row's least-gathered column, that column) when `cold`, else nothing (row order) --
+ * into sorted_rows (int32 [n_rows]) and counts the classes (class_count uint64 [4], device).  lgc_tile_pack turns one
+ * class's slice of sorted_rows into `order` (int32 [n_tiles * R], -1 padded; inside a tile the longest rows first, rank
+ * rho in slot (rho % 4) * R / 4 + rho / 4) and `meta` (int32 [n_tiles], byte bt = longest row of batch bt), n_tiles =
+ * ceil(n_rows / R), R = 16 (width 8) or 8.  table_rows bounds the column ids; workspace >= the _workspace_bytes answer. */
+size_t lgc_tile_classes_workspace_bytes(int64_t n_rows, int64_t table_rows);
+int lgc_tile_classes(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin, int32_t row_end, int32_t max_len,
+                     int32_t cold, int64_t table_rows, void *workspace, size_t workspace_bytes, int32_t *sorted_rows,
+                     uint64_t *class_count, void *stream);
+int lgc_tile_pack(const int32_t *rowptr, const int32_t *sorted_rows, int64_t n_rows, int32_t width, int32_t *order, int32_t *meta,
+                  void *stream);
 
 int lgc_spmm_tiles(const int32_t *order, const int32_t *meta, const lgc_entry *slab, int32_t n_tiles, int32_t width,
                    int32_t tiles_per_wave, int64_t table_rows, const float *x, int64_t x_stride,
@@ -223,6 +254,12 @@ lgc_sweep_plan *lgc_sweep_plan_create(const int32_t *rowptr_host, const lgc_entr
 int lgc_sweep_plan_dims(const lgc_sweep_plan *plan, lgc_sweep_dims *dims);
 int lgc_sweep_plan_export(const lgc_sweep_plan *plan, uint32_t *slabs, int32_t *wave_slab_ptr, int32_t *wave_npieces,
                           int32_t *piece_slot, lgc_multi_row *multi);
+/* The four big arrays straight into caller-provided DEVICE buffers of the sizes lgc_sweep_plan_dims reports (slabs,
+ * wave_slab_ptr, wave_npieces, piece_slot; `multi` stays with lgc_sweep_plan_export: the host splits it by slot count);
+ * synchronises `stream` before returning, so the plan may be freed right away.  Spares a host copy of ~90 MB. */
+int lgc_sweep_plan_export_multi(const lgc_sweep_plan *plan, lgc_multi_row *multi);      /* HOST buffer, [n_rows] */
+int lgc_sweep_plan_upload(const lgc_sweep_plan *plan, uint32_t *slabs, int32_t *wave_slab_ptr, int32_t *wave_npieces,
+                          int32_t *piece_slot, void *stream);
 void lgc_sweep_plan_free(lgc_sweep_plan *plan);
 
 int lgc_sweep_ok(int32_t dim, int64_t table_rows, int64_t x_stride);

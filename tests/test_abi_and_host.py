@@ -379,6 +379,25 @@ def test_argument_errors_of_the_round4_entry_points():
     psv = lambda **kw: lib.lgc_pair_seed_vals(kw.get("g", one), None, None, kw.get("r0", one), one, kw.get("m", 8), kw.get("dim", 64),
                                               kw.get("vals", two), None)
     assert psv(g=None) == -1 and psv(r0=None) == -1 and psv(vals=None) == -1 and psv(m=-1) == -1 and psv(dim=0) == -1 and psv(m=0) == 0
+    tc = lambda **kw: lib.lgc_tile_classes(kw.get("rp", one), one, 0, kw.get("re", 4), kw.get("ml", 32), 1, kw.get("tr", 8),
+                                           kw.get("ws", two), kw.get("wsb", 1 << 20), kw.get("sr", two), kw.get("cc", two), None)
+    assert tc(rp=None) == -1 and tc(sr=None) == -1 and tc(cc=None) == -1 and tc(re=-1) == -1 and tc(tr=2) == -1 and tc(ml=-1) == -1
+    assert tc(ws=None) == -1 and tc(wsb=16) == -3 and tc(ws=ctypes.c_void_p(520)) == -5
+    assert lib.lgc_tile_classes_workspace_bytes(1000, 5000) > 1000 * 20 and lib.lgc_tile_classes_workspace_bytes(-1, 5) == 0
+    tp = lambda **kw: lib.lgc_tile_pack(kw.get("rp", one), kw.get("sr", one), kw.get("n", 8), kw.get("w", 8), kw.get("o", two), two, None)
+    assert tp(rp=None) == -1 and tp(sr=None) == -1 and tp(o=None) == -1 and tp(n=-1) == -1 and tp(w=12) == -1 and tp(n=0) == 0
+    up = lambda **kw: lib.lgc_sweep_plan_upload(kw.get("plan", None), one, one, one, one, None)
+    assert up() == -1 and lib.lgc_sweep_plan_export_multi(None, one) == -1
+    assert lib.lgc_bipartite_split(None, 5, two, None) == -1 and lib.lgc_bipartite_split(one, 5, None, None) == -1
+    assert lib.lgc_bipartite_split(one, -1, two, None) == -1
+    rpc = lambda **kw: lib.lgc_row_plan_count(kw.get("rp", one), 0, kw.get("re", 4), kw.get("sm", 32), kw.get("cl", 256),
+                                              kw.get("ws", two), kw.get("wsb", 1 << 16), kw.get("tot", two), None)
+    assert rpc(rp=None) == -1 and rpc(tot=None) == -1 and rpc(re=-1) == -1 and rpc(sm=-1) == -1 and rpc(cl=0) == -1
+    assert rpc(ws=None) == -1 and rpc(wsb=8) == -3 and rpc(ws=ctypes.c_void_p(520)) == -5
+    assert lib.lgc_row_plan_workspace_bytes(1000) >= 3 * 4004 and lib.lgc_row_plan_workspace_bytes(-1) == 0
+    rpf = lambda **kw: lib.lgc_row_plan_fill(kw.get("rp", one), 0, kw.get("re", 4), 32, kw.get("cl", 256), kw.get("ws", two),
+                                             kw.get("ch", two), two, None)
+    assert rpf(rp=None) == -1 and rpf(ws=None) == -1 and rpf(ch=None) == -1 and rpf(cl=0) == -1 and rpf(re=0) == 0
     bpr = lambda **kw: lib.lgc_bpr_loss(kw.get("s", one), None, kw.get("b", 8), kw.get("size", 8), kw.get("loss", two), kw.get("grad", two),
                                         None)
     assert bpr(loss=None) == -1 and bpr(s=None) == -1 and bpr(grad=None) == -1 and bpr(b=-1) == -1 and bpr(size=0) == -1

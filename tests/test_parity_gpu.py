@@ -1286,6 +1286,47 @@ def test_training_glue_kernels_match_torch(device, dim):
     assert torch.equal(vals.cpu(), torch.cat([gs.view(-1, 1) * w1, gs.view(-1, 1) * w0]))
 
 
+@pytest.mark.parametrize("mode", ["cold", "natural"])
+@pytest.mark.parametrize("max_len", [32, 20, 5])
+def test_device_tile_planner_equals_the_index_arithmetic(device, mode, max_len):
+    """lgc_tile_classes + lgc_tile_pack (four launches) against graph.plan_tile_classes (torch index arithmetic, also the
+    CPU tests' subject): identical order and meta lists, whole graph and a row range, rows without entries included."""
+    from gnn_ecommerce_amd import graph as G
+    g, ei, ew = small_graph(23, 3000, 200, 14000)
+    n = g.num_nodes + 40                                               # 40 isolated nodes: rows with no entries
+    pg = PropGraph(ei.to(device), ew.to(device), n)
+    op = pg.forward_op
+    for lo, hi in ((0, n), (0, g.n_users), (g.n_users, n), (137, 2011)):
+        want = G.plan_tile_classes(op.rowptr, op.entries[:, 0], lo, hi, max_len, mode)
+        got = G.plan_tile_classes_device(op.rowptr, op.entries, lo, hi, max_len, mode)
+        assert [w for w, _, _ in got] == [w for w, _, _ in want]
+        for (w, order, meta), (_, order_w, meta_w) in zip(got, want):
+            assert torch.equal(order, order_w) and torch.equal(meta, meta_w), (lo, hi, w)
+
+
+@pytest.mark.parametrize("short_max,chunk_len", [(0, 1), (0, 7), (4, 16), (32, 256), (100000, 256), (32, 4096)])
+def test_device_row_plan_and_split_equal_the_index_arithmetic(device, short_max, chunk_len):
+    """lgc_row_plan_count / _fill against graph.build_row_plan (the CPU tests' subject), whole graph and row ranges; and
+    lgc_bipartite_split against the two reductions it replaces, on a user|item list, a general list and a list whose ids
+    touch at the split."""
+    from gnn_ecommerce_amd import graph as G
+    g, ei, ew = small_graph(29, 2500, 120, 30000)
+    n = g.num_nodes
+    pg = PropGraph(ei.to(device), ew.to(device), n)
+    rp = pg.forward_op.rowptr
+    for lo, hi in ((0, n), (0, g.n_users), (g.n_users, n), (77, 1999), (5, 5)):
+        want, got = G.build_row_plan(rp, lo, hi, short_max, chunk_len), G.build_row_plan_device(rp, lo, hi, short_max, chunk_len)
+        assert torch.equal(got.chunks, want.chunks) and torch.equal(got.multi, want.multi) and got.n_slots == want.n_slots
+    assert pg.split == g.n_users
+    rng = np.random.default_rng(1)
+    general = torch.from_numpy(rng.integers(300, size=(2, 4000))).to(device)
+    assert PropGraph(general, None, 300).split is None
+    touching = torch.tensor([[0, 1, 2, 5], [5, 4, 3, 2]], device=device)      # min(src,dst) max = 2, max(src,dst) min = 3
+    assert PropGraph(touching, None, 6).split == 3
+    overlap = torch.tensor([[0, 3], [3, 5]], device=device)                    # node 3 on both sides: not bipartite by ranges
+    assert PropGraph(overlap, None, 6).split is None
+
+
 def test_invalidate_after_an_untracked_write_and_late_index_errors(device):
     """ADVICE r1: (1) writes that bypass the version counter are invisible to the caches until invalidate();
     (2) an out-of-range label index surfaces as IndexError at the NEXT scoring call without any added sync."""
