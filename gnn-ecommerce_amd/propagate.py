@@ -356,10 +356,12 @@ _seed_maps = {}
 
 
 def _scratch_key(device: torch.device):
-    """Scratch that must be all zero between uses is owned by one (device, stream) pair: the set / pull / clear sequence
-    of a backward pass is ordered on ITS stream only, so two backward passes on different streams (two models, a
-    DataParallel-style host loop) each get their own buffers instead of reading or clearing each other's flags."""
-    return (device, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    """Scratch that must be all zero between uses is owned by one (device, stream, host thread) triple: the set / pull /
+    clear sequence of a backward pass is ordered on ITS stream and issued by ITS thread only, so two backward passes on
+    different streams or threads (two models, a DataParallel-style host loop, the thread-ranks of
+    tests/test_partition_gpu.py) each get their own buffers instead of reading or clearing each other's flags."""
+    import threading
+    return (device, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0, threading.get_ident())
 
 
 def _seed_map_buffers(device: torch.device, n_cols: int):
