@@ -21,6 +21,7 @@ cpu_baseline = the reference-semantics CPU path (oracle/, a port of the referenc
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -188,18 +189,21 @@ def rank_local_bench(graph, ei, ew, dim, layers, world, ranks, single_hop_s):
         dev = ei.device
         alphas = tuple([1.0 / (layers + 1)] * (layers + 1))
         x0 = synth.xavier_table(graph.num_nodes, dim, SEED, dev)
-        hop_us, train_ms = [], []
+        hop_us, hop_mean_us, train_ms, train_graph_ms = [], [], [], []
         for r in ranks:
             pp = partition.PartitionedPropagator(ei, ew, graph.n_users, graph.n_items, r, world)
             for _ in range(3):
                 pp.propagate_sum(x0, alphas)
             torch.cuda.synchronize()
             reps = 20
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                pp.propagate_sum(x0, alphas)
-            torch.cuda.synchronize()
-            hop_us.append((time.perf_counter() - t0) / reps / layers * 1e6)
+            times = []
+            for _ in range(reps):                   # each forward timed on its own: the MEDIAN is reported -- one allocator
+                t0 = time.perf_counter()            # stall (a fresh 434 MB block: tens of ms) in a 20-forward loop otherwise
+                pp.propagate_sum(x0, alphas)        # shows up as +400 us per hop (seen once in four runs)
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+            hop_us.append(statistics.median(times) / layers * 1e6)
+            hop_mean_us.append(sum(times) / reps / layers * 1e6)
             w = torch.nn.Parameter(x0.clone())
             opt = HipAdam([w], 0.005, row_ranges=pp.owned_row_ranges())
             gen = torch.Generator().manual_seed(SEED)
@@ -217,17 +221,37 @@ def rank_local_bench(graph, ei, ew, dim, layers, world, ranks, single_hop_s):
             for _ in range(3):
                 step()
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
+            times = []
             for _ in range(reps):
-                step()
+                t0 = time.perf_counter()
+                step()                               # ends in two .item() syncs
+                times.append(time.perf_counter() - t0)
+            train_ms.append(statistics.median(times) * 1e3)
+            # the same step as trainer.PartitionedTrainer records it: HIP graphs between the (stubbed) collectives
+            from gnn_ecommerce_amd.trainer import PartitionedTrainer
+            tr = PartitionedTrainer(pp, x0.clone(), alphas, lr=0.005, decay=1e-4, batch=1024, graphs=True)
+            ids = [(torch.randint(0, graph.n_users, (1024,), generator=gen).to(dev),
+                    (torch.randint(0, graph.n_items, (1024,), generator=gen) + graph.n_users).to(dev),
+                    (torch.randint(0, graph.n_items, (1024,), generator=gen) + graph.n_users).to(dev)) for _ in range(4)]
+            for k in range(4):
+                tr.step(*ids[k % 4])
             torch.cuda.synchronize()
-            train_ms.append((time.perf_counter() - t0) / reps * 1e3)
-            del pp, w, opt
+            times = []
+            for k in range(reps):
+                t0 = time.perf_counter()
+                tr.step(*ids[k % 4]).tolist()        # one host sync per step
+                times.append(time.perf_counter() - t0)
+            train_graph_ms.append(statistics.median(times) * 1e3)
+            del pp, w, opt, tr
         worst = max(hop_us)
         return {"world": world, "ranks_measured": list(ranks), "us_per_hop": worst, "us_per_hop_by_rank": hop_us,
-                "ceiling_x": single_hop_s * 1e6 / worst, "train_ms_per_step": max(train_ms),
+                "us_per_hop_mean_by_rank": hop_mean_us, "ceiling_x": single_hop_s * 1e6 / worst,
+                "train_ms_per_step": max(train_graph_ms), "train_ms_per_step_autograd": max(train_ms),
                 "what": "local work of one rank per hop / per training step on this one GPU, every all-reduce stubbed out; "
-                        "ceiling_x = this run's single-GPU hop time / us_per_hop (no exchange cost in it)"}
+                        "medians of 20 individually timed forwards / steps (means beside them); ceiling_x = this run's "
+                        "single-GPU hop time / us_per_hop (no exchange cost in it); train_ms_per_step = "
+                        "trainer.PartitionedTrainer with the step recorded as HIP graphs between the collectives, "
+                        "train_ms_per_step_autograd = partitioned_bpr_loss + backward() + optim.Adam(row_ranges)"}
     finally:
         dist.all_reduce = real_all_reduce
 

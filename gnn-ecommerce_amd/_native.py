@@ -106,7 +106,7 @@ SIGNATURES = {
     "lgc_bpr_loss": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "lgc_pair_seed_vals": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "lgc_seed_prepare": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                 c_void_p, c_void_p]),
+                                 c_void_p, c_void_p, c_void_p]),
     "lgc_seed_flags": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int32, c_void_p]),
     "lgc_seed_pull": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int32, c_void_p]),

@@ -424,13 +424,13 @@ class DeviceOps:
             return seed_prepare_reference(rows, split, n, flag, slot)
         rows = rows.contiguous()
         i64 = dict(dtype=torch.int64, device=dev)
-        buf = torch.empty((4, max(m, 1)), **i64)
+        buf = torch.empty((5, max(m, 1)), **i64)               # four outputs + the sorted keys in between the two launches
         perm = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
         lib = _native.load()
         with torch.cuda.device(dev):
             code = lib.lgc_seed_prepare(_native.ptr(rows), m, int(split), int(n), _native.ptr(buf[0]), _native.ptr(perm),
                                         _native.ptr(buf[1]), _native.ptr(buf[2]), _native.ptr(buf[3]), _native.ptr(flag),
-                                        _native.ptr(slot), _native.stream_of(dev))
+                                        _native.ptr(slot), _native.ptr(buf[4]), _native.stream_of(dev))
         _native.check(code, "lgc_seed_prepare")
         return buf[0, :m], perm[:m], buf[1, :m], buf[2, :m], buf[3, :m]
 

@@ -352,7 +352,8 @@ int lgc_segment_sum(const int64_t *key_sorted, const int64_t *dest, const float 
  *                    vals[m] = g_m * rows1[m], vals[n_pairs + m] = g_m * rows0[m], g_m = mask[m] ? grad_scores[m] *
  *                    (*grad_scale) : 0 (grad_scale: DEVICE scalar or NULL; mask uint8 [n_pairs] or NULL).
  * lgc_seed_prepare   sorts the m <= LGC_SEED_MAX node ids `rows` (int64; ids outside [0, n_nodes) count as "no row" and
- *                    come out as -1, first) and derives, per sorted position t: rows_sorted[t]; perm[t] (int32, the input
+ *                    come out as -1, first; two launches: every id ranked by counting, then one thread per sorted position)
+ *                    and derives, per sorted position t: rows_sorted[t]; perm[t] (int32, the input
  *                    position: a stable sort); dest_item[t] = the row if t heads a run of an item row (row >= split) else
  *                    -1; dest_slot[t] = t, dest_user[t] = the row if t heads a run of a user row (row < split) else -1 --
  *                    the three destination lists of lgc_segment_sum for the item block of the seed table, the compact
@@ -369,7 +370,7 @@ int lgc_pair_seed_vals(const float *grad_scores, const uint8_t *mask, const floa
                        const float *rows1, int64_t n_pairs, int32_t dim, float *vals, void *stream);
 int lgc_seed_prepare(const int64_t *rows, int64_t m, int64_t split, int64_t n_nodes, int64_t *rows_sorted, int32_t *perm,
                      int64_t *dest_item, int64_t *dest_slot, int64_t *dest_user, uint8_t *col_flag, int32_t *col_slot,
-                     void *stream);
+                     uint64_t *scratch /* [m], device */, void *stream);
 int lgc_seed_flags(const int64_t *rows_sorted, int64_t m, int64_t split, uint8_t *col_flag, int32_t value, void *stream);
 
 /* Seeded pull (first hop of the backward pass, loss.backward() at src/train_lightgcn.py:146): the incoming gradient has

@@ -8,7 +8,7 @@
 set -o pipefail
 tag=${1:?tag}; shift
 args=("$@")
-[ ${#args[@]} -eq 0 ] && args=(--steps 10 --warmup 2 --no-cpu-baseline --no-deep)
+[ ${#args[@]} -eq 0 ] && args=(--steps 10 --warmup 2 --no-cpu-baseline --no-deep --no-train --no-rank-local)
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 out=gpurun_out/prof_$tag
 mkdir -p "$out"

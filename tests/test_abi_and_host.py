@@ -367,9 +367,11 @@ def test_argument_errors_of_the_round4_entry_points():
     lib = _native.load()
     one, two = ctypes.c_void_p(256), ctypes.c_void_p(512)
     prep = lambda **kw: lib.lgc_seed_prepare(kw.get("rows", one), kw.get("m", 8), kw.get("split", 4), kw.get("n", 10), one, one,
-                                             kw.get("di", one), one, one, kw.get("flag", None), kw.get("slot", None), None)
+                                             kw.get("di", one), one, one, kw.get("flag", None), kw.get("slot", None),
+                                             kw.get("scratch", two), None)
     assert prep(m=-1) == -4 and prep(m=8193) == -4 and prep(rows=None) == -1 and prep(di=None) == -1 and prep(split=11) == -1
     assert prep(flag=one) == -1 and prep(slot=one) == -1 and prep(m=0) == 0       # flag and slot: both or neither
+    assert prep(scratch=None) == -1
     flags = lambda **kw: lib.lgc_seed_flags(kw.get("rows", one), kw.get("m", 8), 4, kw.get("flag", two), kw.get("value", 0), None)
     assert flags(rows=None) == -1 and flags(flag=None) == -1 and flags(m=-1) == -1 and flags(value=256) == -1 and flags(m=0) == 0
     pdr = lambda **kw: lib.lgc_pair_dot_rows(kw.get("emb", one), kw.get("stride", 64), kw.get("dim", 64), 100, kw.get("i0", one),
