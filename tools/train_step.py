@@ -36,7 +36,7 @@ args = ap.parse_args()
 dev = torch.device("cuda:0")
 g = synth.make_bipartite(**synth.CONFIG_COSMETICS, seed=0)
 ei, ew = g.coo(dev)
-if args.world > 1:
+if args.world > 1 or args.trainer != "autograd":     # --world 1 --trainer graphs: the single-GPU step as recorded launches
     import torch.distributed as dist
     from gnn_ecommerce_amd import partition
     from gnn_ecommerce_amd.optim import Adam as HipAdam
