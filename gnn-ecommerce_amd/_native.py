@@ -91,6 +91,13 @@ SIGNATURES = {
     "lgc_sweep_plan_upload": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lgc_sweep_plan_export_multi": (c_int, [c_void_p, c_void_p]),
     "lgc_sweep_plan_free": (None, [c_void_p]),
+    "lgc_sweep_dplan_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, POINTER(SweepCfg)]),
+    "lgc_sweep_dplan_create": (c_void_p, [c_void_p, c_void_p, c_int32, c_int32, c_int64, c_int64, c_int32, c_int32,
+                                          POINTER(SweepCfg), c_void_p, c_size_t, c_void_p, POINTER(c_int)]),
+    "lgc_sweep_dplan_dims": (c_int, [c_void_p, POINTER(SweepDims)]),
+    "lgc_sweep_dplan_fill": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lgc_sweep_dplan_export_multi": (c_int, [c_void_p, c_void_p]),
+    "lgc_sweep_dplan_free": (None, [c_void_p]),
     "lgc_sweep_ok": (c_int, [c_int32, c_int64, c_int64]),
     "lgc_spmm_sweep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p,
                                c_int32, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float, c_float,

@@ -2153,6 +2153,19 @@ bool aligned_to(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p
 // ----------------------------------------------------------------------------------------
 // Band-sweep planner (host code, host pointers): see k_sweep
 // ----------------------------------------------------------------------------------------
+struct lgc_sweep_dplan {          // host handle of the device planner between _create and _fill
+    lgc_sweep_cfg cfg{};
+    lgc_sweep_dims dims{};
+    int32_t row_begin = 0;
+    std::vector<lgc_multi_row> multi;
+    std::vector<int32_t> wave_npieces, piece_slot, wave_item_ptr, wave_slab_ptr;
+    // device pointers into the caller's workspace (must stay alive until _fill has returned)
+    const unsigned long long *keys = nullptr;
+    const int32_t *idx = nullptr, *d_item_ptr = nullptr;
+    const lgc_entry *sorted = nullptr;
+    int32_t *d_slab_ptr = nullptr;
+};
+
 struct lgc_sweep_plan {
     lgc_sweep_dims dims{};
     std::vector<uint32_t> slabs;          // n_slabs * 256 dwords
@@ -2199,6 +2212,93 @@ void parallel_each(int64_t n, F &&f) {
     std::vector<std::thread> th;
     for (int64_t i = 0; i < n; ++i) th.emplace_back([&f, i] { f(i); });
     for (auto &t : th) t.join();
+}
+
+// Phases "pieces" and C of the sweep planner, from the run length of every (row, band) pair alone -- shared by the host
+// planner (sweep_plan_build) and the device planner (lgc_sweep_dplan_*): piece cap, rounds, the piece list (slots
+// contiguous per row, band-major), the rows' slot ranges, and the deal of the pieces over the wavefronts.
+struct PlanPieces {
+    int PCAP = 0, rounds = 0;
+    int64_t n_waves = 0;
+    std::vector<SweepPiece> pieces;
+    std::vector<lgc_multi_row> multi;
+    std::vector<std::vector<int32_t>> wave_pieces;
+};
+
+int plan_pieces_and_deal(const std::vector<int32_t> &run_len, int64_t n_rows, int32_t row_begin, const lgc_sweep_cfg &cfg,
+                         PlanPieces &out) {
+    const int NB = cfg.n_bands, WPBR = cfg.waves_per_band_round, CAP = cfg.row_cap;
+    // piece length cap: the configured one, raised in steps of 16 while a longer cap saves a whole round
+    auto rounds_for = [&](int64_t pcap) {
+        std::vector<int64_t> per_band((size_t)NB, 0);
+        for (int64_t i = 0; i < n_rows; ++i)
+            for (int b = 0; b < NB; ++b) per_band[(size_t)b] += (run_len[(size_t)i * NB + b] + pcap - 1) / pcap;
+        const int64_t most = *std::max_element(per_band.begin(), per_band.end());
+        return (int)std::max<int64_t>(1, (most + (int64_t)WPBR * CAP - 1) / ((int64_t)WPBR * CAP));
+    };
+    int PCAP = cfg.piece_cap;
+    const int fewest = rounds_for(int64_t(1) << 40);
+    while (PCAP < 4 * cfg.piece_cap && rounds_for(PCAP) > fewest) PCAP += 16;
+    const int rounds = rounds_for(PCAP);
+    // pieces: long runs cut into near-equal parts of <= PCAP entries; slots are contiguous per row, band-major
+    std::vector<SweepPiece> &pieces = out.pieces;
+    int64_t row_start = 0;
+    pieces.reserve((size_t)n_rows * NB + 1024);
+    out.multi.resize((size_t)n_rows);
+    for (int64_t i = 0; i < n_rows; ++i) {
+        lgc_multi_row &mr = out.multi[(size_t)i];
+        mr.row = row_begin + (int32_t)i;
+        mr.slot_begin = (int32_t)pieces.size();
+        mr.reserved = 0;
+        int64_t k = row_start;                      // first entry of the row in the column-sorted array
+        for (int b = 0; b < NB; ++b) {
+            const int64_t cnt = run_len[(size_t)i * NB + b];
+            if (cnt > 0) {
+                const int64_t parts = (cnt + PCAP - 1) / PCAP, per = (cnt + parts - 1) / parts;
+                for (int64_t q = 0; q < cnt; q += per)
+                    pieces.push_back({(int32_t)(k + q), (int32_t)std::min<int64_t>(per, cnt - q), b});
+            }
+            k += cnt;
+        }
+        row_start = k;
+        mr.slot_end = (int32_t)pieces.size();
+    }
+    const int64_t n_pieces = (int64_t)pieces.size();
+    // C. pieces -> waves, band by band: heaviest first, dealt out in serpentine order (equal piece counts, close loads)
+    std::vector<std::vector<int32_t>> by_band((size_t)NB);
+    for (int64_t i = 0; i < n_pieces; ++i) by_band[(size_t)pieces[(size_t)i].band].push_back((int32_t)i);
+    const int64_t U = (int64_t)rounds * WPBR;           // waves per band
+    const int64_t n_waves = U * NB;
+    std::vector<std::vector<int32_t>> &wave_pieces = out.wave_pieces;
+    wave_pieces.assign((size_t)n_waves, {});
+    // a band's pieces only ever go to that band's wavefronts (w encodes b): the bands are dealt out in parallel
+    parallel_each(NB, [&](int64_t b) {
+        auto &v = by_band[(size_t)b];
+        std::stable_sort(v.begin(), v.end(), [&](int32_t a, int32_t c) { return pieces[(size_t)a].count > pieces[(size_t)c].count; });
+        const bool by_weight = cfg.round_order >= 1;
+        const size_t per_round = ((v.size() + (size_t)rounds - 1) / (size_t)rounds);
+        for (size_t k = 0; k < v.size(); ++k) {
+            int64_t u;
+            if (by_weight) {   // heaviest pieces fill round 0, the next round 1, ...: serpentine inside the round
+                const int64_t rr = (int64_t)(k / per_round), kk = (int64_t)(k % per_round);
+                const int64_t lap = kk / WPBR, pos = kk % WPBR;
+                u = rr * WPBR + ((lap & 1) ? (WPBR - 1 - pos) : pos);
+            } else {
+                const int64_t lap = (int64_t)(k / (size_t)U), pos = (int64_t)(k % (size_t)U);
+                u = (lap & 1) ? (U - 1 - pos) : pos;
+            }
+            const int64_t r = u / WPBR, j = u % WPBR;
+            // bands side by side: block = (r, j / 4, band), band = block % NB (one band per XCD, all bands at once)
+            const int64_t w = ((r * (WPBR / 4) + j / 4) * NB + b) * 4 + (j % 4);
+            wave_pieces[(size_t)w].push_back(v[k]);
+        }
+    });
+    for (auto &wp : wave_pieces)
+        if ((int)wp.size() > CAP) return LGC_E_INVAL;   // cannot happen: ceil(n / U) <= CAP
+    out.PCAP = PCAP;
+    out.rounds = rounds;
+    out.n_waves = n_waves;
+    return 0;
 }
 
 int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin, int32_t row_end,
@@ -2254,71 +2354,16 @@ int sweep_plan_build(lgc_sweep_plan &pl, const int32_t *rowptr, const lgc_entry 
         }
     });
     lap("B rows sorted by column");
-    // piece length cap: the configured one, raised in steps of 16 while a longer cap saves a whole round
-    auto rounds_for = [&](int64_t pcap) {
-        std::vector<int64_t> per_band((size_t)NB, 0);
-        for (int64_t i = 0; i < n_rows; ++i)
-            for (int b = 0; b < NB; ++b) per_band[(size_t)b] += (run_len[(size_t)i * NB + b] + pcap - 1) / pcap;
-        const int64_t most = *std::max_element(per_band.begin(), per_band.end());
-        return (int)std::max<int64_t>(1, (most + (int64_t)WPBR * CAP - 1) / ((int64_t)WPBR * CAP));
-    };
-    int PCAP = cfg.piece_cap;
-    const int fewest = rounds_for(int64_t(1) << 40);
-    while (PCAP < 4 * cfg.piece_cap && rounds_for(PCAP) > fewest) PCAP += 16;
-    const int rounds = rounds_for(PCAP);
-    // pieces: long runs cut into near-equal parts of <= PCAP entries; slots are contiguous per row, band-major
-    std::vector<SweepPiece> pieces;
-    pieces.reserve((size_t)n_rows * NB + 1024);
-    pl.multi.resize((size_t)n_rows);
-    for (int64_t i = 0; i < n_rows; ++i) {
-        lgc_multi_row &mr = pl.multi[(size_t)i];
-        mr.row = row_begin + (int32_t)i;
-        mr.slot_begin = (int32_t)pieces.size();
-        mr.reserved = 0;
-        int64_t k = rowptr[row_begin + i] - e0;
-        for (int b = 0; b < NB; ++b) {
-            const int64_t cnt = run_len[(size_t)i * NB + b];
-            if (cnt > 0) {
-                const int64_t parts = (cnt + PCAP - 1) / PCAP, per = (cnt + parts - 1) / parts;
-                for (int64_t q = 0; q < cnt; q += per)
-                    pieces.push_back({(int32_t)(k + q), (int32_t)std::min<int64_t>(per, cnt - q), b});
-            }
-            k += cnt;
-        }
-        mr.slot_end = (int32_t)pieces.size();
+    PlanPieces pp;
+    {
+        const int rc = plan_pieces_and_deal(run_len, n_rows, row_begin, cfg, pp);
+        if (rc != 0) return rc;
     }
-    const int64_t n_pieces = (int64_t)pieces.size();
-    lap("pieces");
-    // C. pieces -> waves, band by band: heaviest first, dealt out in serpentine order (equal piece counts, close loads)
-    std::vector<std::vector<int32_t>> by_band((size_t)NB);
-    for (int64_t i = 0; i < n_pieces; ++i) by_band[(size_t)pieces[(size_t)i].band].push_back((int32_t)i);
-    const int64_t U = (int64_t)rounds * WPBR;           // waves per band
-    const int64_t n_waves = U * NB;
-    std::vector<std::vector<int32_t>> wave_pieces((size_t)n_waves);
-    // a band's pieces only ever go to that band's wavefronts (w encodes b): the bands are dealt out in parallel
-    parallel_each(NB, [&](int64_t b) {
-        auto &v = by_band[(size_t)b];
-        std::stable_sort(v.begin(), v.end(), [&](int32_t a, int32_t c) { return pieces[(size_t)a].count > pieces[(size_t)c].count; });
-        const bool by_weight = cfg.round_order >= 1;
-        const size_t per_round = ((v.size() + (size_t)rounds - 1) / (size_t)rounds);
-        for (size_t k = 0; k < v.size(); ++k) {
-            int64_t u;
-            if (by_weight) {   // heaviest pieces fill round 0, the next round 1, ...: serpentine inside the round
-                const int64_t rr = (int64_t)(k / per_round), kk = (int64_t)(k % per_round);
-                const int64_t lap = kk / WPBR, pos = kk % WPBR;
-                u = rr * WPBR + ((lap & 1) ? (WPBR - 1 - pos) : pos);
-            } else {
-                const int64_t lap = (int64_t)(k / (size_t)U), pos = (int64_t)(k % (size_t)U);
-                u = (lap & 1) ? (U - 1 - pos) : pos;
-            }
-            const int64_t r = u / WPBR, j = u % WPBR;
-            // bands side by side: block = (r, j / 4, band), band = block % NB (one band per XCD, all bands at once)
-            const int64_t w = ((r * (WPBR / 4) + j / 4) * NB + b) * 4 + (j % 4);
-            wave_pieces[(size_t)w].push_back(v[k]);
-        }
-    });
-    for (auto &wp : wave_pieces)
-        if ((int)wp.size() > CAP) return LGC_E_INVAL;   // cannot happen: ceil(n / U) <= CAP
+    const int PCAP = pp.PCAP, rounds = pp.rounds;
+    std::vector<SweepPiece> &pieces = pp.pieces;
+    pl.multi = pp.multi;
+    const int64_t n_pieces = (int64_t)pieces.size(), n_waves = pp.n_waves;
+    std::vector<std::vector<int32_t>> &wave_pieces = pp.wave_pieces;
     lap("C pieces -> waves");
     // D. per wave: merged column-sorted list -> conflict-free steps of 4 -> slabs of 32 steps
     const uint32_t PAD_X = 0x00FFFFFFu | ((uint32_t)CAP << 24);    // out-of-range column, dummy accumulator row
@@ -2488,6 +2533,168 @@ int prepare_tiles(TilePrep &out, const int32_t *order, const int32_t *meta, cons
     }
     out.p = p;
     return 0;
+}
+
+
+// ----------------------------------------------------------------------------------------
+// The sweep planner with its bulk work on the device (lgc_sweep_dplan_*): same plan, bit for bit, as sweep_plan_build
+// ----------------------------------------------------------------------------------------
+// The host planner copies the half's 81 MB of entries to the host, sorts and scans them there and copies 87 MB of slabs
+// back: 0.11-0.15 s.  Here the entries never leave the device:
+//   A  column histogram (k_dp_hist) -> host: band bounds (a 1.6 M-element prefix walk)
+//   B  every row sorted by column = ONE stable radix sort of (row << 24 | col) keys; run length of every (row, band)
+//   -> host: pieces, rounds, deal (plan_pieces_and_deal: needs the run lengths only, 1.7 MB)
+//   D  every wavefront's merged column-sorted list = ONE stable radix sort of (wave << 40 | col << 16 | piece << 8 | position
+//      in the piece) keys (the low 40 bits inverted for wavefronts that walk their band downwards); then the greedy
+//      conflict-free step builder, one WAVEFRONT per list: the host's scan looks at the next `lookahead` <= 64 undone
+//      entries -- exactly one wavefront of lanes.  A step takes the first undone entry, then the first whose piece differs,
+//      ... (<= GROUPS ballots), drops the taken lanes, closes the gaps through LDS and refills from the list.  Two passes:
+//      count the steps of every list (-> slab offsets), then write the slabs.
+__global__ void k_dp_hist(const lgc_entry *__restrict__ entries, int64_t e0, int64_t ne, int32_t col_lo, int32_t n_cols,
+                          int32_t *__restrict__ hist, int32_t *__restrict__ bad) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ne) return;
+    const int32_t c = entries[e0 + k].col - col_lo;
+    if (c < 0 || c >= n_cols) *bad = 1;
+    else atomicAdd(&hist[c], 1);
+}
+
+__global__ void k_dp_row_keys(const int32_t *__restrict__ rowptr, int32_t row_begin, int32_t n_rows,
+                              const lgc_entry *__restrict__ entries, int64_t e0, int64_t ne,
+                              unsigned long long *__restrict__ keys, int32_t *__restrict__ idx) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ne) return;
+    int lo = 0, hi = n_rows - 1;                      // the row whose entry range holds e0 + k
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int64_t)rowptr[row_begin + mid] - e0 <= k) lo = mid;
+        else hi = mid - 1;
+    }
+    keys[k] = ((unsigned long long)lo << 24) | (unsigned)(entries[e0 + k].col & 0xFFFFFF);
+    idx[k] = (int32_t)k;
+}
+
+struct DpBounds { int32_t b[65]; };
+
+__global__ void k_dp_gather(const lgc_entry *__restrict__ entries, int64_t e0, int64_t ne,
+                            const unsigned long long *__restrict__ keys_sorted, const int32_t *__restrict__ idx_sorted,
+                            DpBounds bound, int32_t nb, lgc_entry *__restrict__ sorted, int32_t *__restrict__ run_len) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ne) return;
+    const lgc_entry ent = entries[e0 + idx_sorted[k]];
+    sorted[k] = ent;
+    const int64_t row = (int64_t)(keys_sorted[k] >> 24);
+    int b = 0;
+    while (b + 1 < nb && ent.col >= bound.b[b + 1]) ++b;
+    atomicAdd(&run_len[row * nb + b], 1);
+}
+
+struct DpPiece { int32_t begin, count, wave, lp; };
+
+__global__ void k_dp_item_keys(const DpPiece *__restrict__ pieces, int64_t n_pieces, const lgc_entry *__restrict__ sorted,
+                               int32_t wpbr, int32_t nb, int32_t serpentine, unsigned long long *__restrict__ keys,
+                               int32_t *__restrict__ idx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pieces) return;
+    const DpPiece pc = pieces[i];
+    const bool down = serpentine && (((pc.wave / 4) / nb) / (wpbr / 4)) % 2 == 1;
+    const unsigned long long mask = (1ull << 40) - 1;
+    for (int32_t j = 0; j < pc.count; ++j) {
+        unsigned long long low = ((unsigned long long)(unsigned)(sorted[pc.begin + j].col & 0xFFFFFF) << 16) |
+                                 ((unsigned long long)pc.lp << 8) | (unsigned)j;
+        if (down) low = ~low & mask;
+        keys[pc.begin + j] = ((unsigned long long)pc.wave << 40) | low;
+        idx[pc.begin + j] = pc.begin + j;
+    }
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(kBlock) void k_dp_steps(const unsigned long long *__restrict__ keys, const int32_t *__restrict__ idx,
+                                                    const lgc_entry *__restrict__ sorted, const int32_t *__restrict__ wave_item_ptr,
+                                                    int32_t n_waves, int32_t groups, int32_t lookahead, int32_t wpbr, int32_t nb,
+                                                    int32_t serpentine, uint32_t pad_x, int32_t *__restrict__ wave_steps,
+                                                    int32_t *__restrict__ wave_pad, const int32_t *__restrict__ wave_slab_ptr,
+                                                    uint32_t *__restrict__ slabs) {
+    __shared__ uint32_t buf_cp[kBlock], buf_v[kBlock];
+    const int lane = threadIdx.x & (kWave - 1), wib = threadIdx.x / kWave;
+    const int w = blockIdx.x * (kBlock / kWave) + wib;
+    if (w >= n_waves) return;                                     // wave-uniform
+    const int32_t begin = wave_item_ptr[w], end = wave_item_ptr[w + 1];
+    const bool down = serpentine && (((w / 4) / nb) / (wpbr / 4)) % 2 == 1;
+    const unsigned long long mask = (1ull << 40) - 1;
+    const int slab_dwords = 64 * groups;
+    uint32_t *cp_buf = buf_cp + wib * kWave, *v_buf = buf_v + wib * kWave;
+    auto load = [&](int32_t t, uint32_t &cp, uint32_t &v) {       // list item t: column | piece << 24, value bits
+        unsigned long long low = keys[t] & mask;
+        if (down) low = ~low & mask;
+        cp = (uint32_t)((low >> 16) & 0xFFFFFF) | ((uint32_t)((low >> 8) & 0xFF) << 24);
+        v = __float_as_uint(sorted[idx[t]].val);
+    };
+    int32_t next = begin;
+    uint32_t cp = 0, v = 0;
+    bool valid = lane < lookahead && next + lane < end;
+    if (valid) load(next + lane, cp, v);
+    next += min(lookahead, end - next);
+    int32_t step = 0, pad = 0;
+    while (true) {
+        const unsigned long long live = __ballot(valid);
+        if (live == 0) break;
+        const int sl = step & 31;
+        uint32_t *slab = nullptr;
+        if constexpr (WRITE) {
+            slab = slabs + ((int64_t)wave_slab_ptr[w] + (step >> 5)) * slab_dwords;
+            if (sl == 0) {                                        // a fresh slab: every step padded until overwritten
+                for (int i = lane; i < slab_dwords / 2; i += kWave) { slab[2 * i] = pad_x; slab[2 * i + 1] = 0u; }
+                __builtin_amdgcn_s_waitcnt(0);                    // the padding lands before this wavefront's entries
+            }
+        }
+        unsigned long long remaining = live, taken = 0;
+        int n_used = 0;
+        for (int g = 0; g < groups && remaining != 0; ++g) {
+            const int j = __builtin_ctzll(remaining);             // the first undone entry whose piece is still free
+            const uint32_t pj = __shfl(cp, j) >> 24;
+            taken |= 1ull << j;
+            if constexpr (WRITE) {
+                if (lane == j) {
+                    const int at = (16 * g + (sl >> 1)) * 4 + 2 * (sl & 1);
+                    slab[at] = cp;
+                    slab[at + 1] = v;
+                }
+            }
+            remaining &= ~__ballot(valid && (cp >> 24) == pj);
+            ++n_used;
+        }
+        pad += groups - n_used;
+        ++step;
+        // close the gaps: survivors keep their order, the list refills the tail of the window
+        const unsigned long long surv = live & ~taken;
+        const int n_surv = __builtin_popcountll(surv);
+        const bool keep = (surv >> lane) & 1;
+        if (keep) {
+            const int pos = __builtin_popcountll(surv & ((1ull << lane) - 1));
+            cp_buf[pos] = cp;
+            v_buf[pos] = v;
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < n_surv) {
+            cp = cp_buf[lane];
+            v = v_buf[lane];
+            valid = true;
+        } else {
+            const int32_t t = next + (lane - n_surv);
+            valid = lane < lookahead && t < end;
+            if (valid) load(t, cp, v);
+        }
+        __builtin_amdgcn_wave_barrier();
+        next += min(max(lookahead - n_surv, 0), end - next);
+    }
+    if constexpr (!WRITE) {
+        if (lane == 0) {
+            wave_steps[w] = step;
+            wave_pad[w] = pad;
+        }
+    }
 }
 
 }  // namespace
@@ -2885,6 +3092,265 @@ int lgc_sweep_plan_upload(const lgc_sweep_plan *plan, uint32_t *slabs, int32_t *
 }
 
 void lgc_sweep_plan_free(lgc_sweep_plan *plan) { delete plan; }
+
+
+// ---- device planner (see the kernels k_dp_*) ----------------------------------------------------------------------
+namespace {
+struct DplanWs {
+    int32_t *hist, *run_len, *idx_a, *idx_b, *item_ptr, *steps, *pad, *slab_ptr, *bad;
+    unsigned long long *keys_a, *keys_b;
+    lgc_entry *sorted;
+    DpPiece *pieces;
+    void *cub;
+    size_t cub_bytes, total;
+};
+
+int64_t dplan_max_pieces(int64_t ne, int64_t n_rows, const lgc_sweep_cfg &cfg) {
+    return n_rows * cfg.n_bands + ne / std::max(1, cfg.piece_cap) + 16;
+}
+
+int64_t dplan_max_waves(int64_t ne, int64_t n_rows, const lgc_sweep_cfg &cfg) {
+    const int64_t per_round = (int64_t)cfg.waves_per_band_round * cfg.row_cap;
+    const int64_t rounds = (dplan_max_pieces(ne, n_rows, cfg) + per_round - 1) / per_round + 1;
+    return rounds * cfg.waves_per_band_round * cfg.n_bands;
+}
+
+DplanWs dplan_carve(void *base, int64_t ne, int64_t n_rows, int64_t n_cols, const lgc_sweep_cfg &cfg) {
+    DplanWs ws{};
+    size_t cb = 0;
+    unsigned long long *nk = nullptr;
+    int32_t *nv = nullptr;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, cb, nk, nk, nv, nv, (int)std::max<int64_t>(ne, 1), 0, 64, (hipStream_t)0);
+    const uintptr_t p = reinterpret_cast<uintptr_t>(base);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t at = off; off += align_up(std::max<size_t>(bytes, 4), 256); return p + at; };
+    const int64_t mw = dplan_max_waves(ne, n_rows, cfg);
+    ws.hist = reinterpret_cast<int32_t *>(take((size_t)n_cols * 4));
+    ws.run_len = reinterpret_cast<int32_t *>(take((size_t)n_rows * cfg.n_bands * 4));
+    ws.keys_a = reinterpret_cast<unsigned long long *>(take((size_t)ne * 8));
+    ws.keys_b = reinterpret_cast<unsigned long long *>(take((size_t)ne * 8));
+    ws.idx_a = reinterpret_cast<int32_t *>(take((size_t)ne * 4));
+    ws.idx_b = reinterpret_cast<int32_t *>(take((size_t)ne * 4));
+    ws.sorted = reinterpret_cast<lgc_entry *>(take((size_t)ne * sizeof(lgc_entry)));
+    ws.pieces = reinterpret_cast<DpPiece *>(take((size_t)dplan_max_pieces(ne, n_rows, cfg) * sizeof(DpPiece)));
+    ws.item_ptr = reinterpret_cast<int32_t *>(take((size_t)(mw + 1) * 4));
+    ws.steps = reinterpret_cast<int32_t *>(take((size_t)mw * 4));
+    ws.pad = reinterpret_cast<int32_t *>(take((size_t)mw * 4));
+    ws.slab_ptr = reinterpret_cast<int32_t *>(take((size_t)(mw + 1) * 4));
+    ws.bad = reinterpret_cast<int32_t *>(take(4));
+    ws.cub = reinterpret_cast<void *>(take(cb));
+    ws.cub_bytes = cb;
+    ws.total = off + 256;
+    return ws;
+}
+
+bool dplan_cfg_ok(const lgc_sweep_cfg *cfg) {
+    return cfg && cfg->n_bands >= 1 && cfg->n_bands <= 64 && cfg->waves_per_band_round >= 4 && cfg->waves_per_band_round % 4 == 0 &&
+           cfg->row_cap >= 1 && cfg->row_cap <= 254 && cfg->piece_cap >= 1 && cfg->piece_cap <= 64 && cfg->lookahead >= 4 &&
+           cfg->lookahead <= 64 && (cfg->groups == 0 || cfg->groups == 2 || cfg->groups == 4) && cfg->round_order >= 0 &&
+           cfg->round_order <= 2;
+}
+}  // namespace
+
+size_t lgc_sweep_dplan_workspace_bytes(int64_t n_entries, int64_t n_rows, int64_t n_cols, const lgc_sweep_cfg *cfg) {
+    if (!dplan_cfg_ok(cfg) || n_entries < 0 || n_rows < 0 || n_cols <= 0 || n_entries >= INT32_MAX) return 0;
+    return dplan_carve(nullptr, n_entries, n_rows, n_cols, *cfg).total;
+}
+
+lgc_sweep_dplan *lgc_sweep_dplan_create(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin, int32_t row_end,
+                                        int64_t first_entry, int64_t n_entries, int32_t col_lo, int32_t col_hi,
+                                        const lgc_sweep_cfg *cfg, void *workspace, size_t workspace_bytes, void *stream_,
+                                        int *code) {
+    auto fail = [&](int rc) -> lgc_sweep_dplan * {
+        if (code) *code = rc;
+        return nullptr;
+    };
+    // piece_cap <= 64 and lookahead <= 64: the composite sort key keeps 8 bits for an entry's position in its piece (pieces
+    // hold up to 4 x piece_cap entries) and the step builder's window is one wavefront; other settings -> the host planner
+    if (!dplan_cfg_ok(cfg)) return fail(LGC_E_RANGE);
+    if (!rowptr || row_begin < 0 || row_end < row_begin || first_entry < 0 || n_entries < 0 || col_lo < 0 || col_hi <= col_lo ||
+        col_hi > 0xFFFFFF || n_entries >= INT32_MAX || (n_entries > 0 && (!entries || !workspace)))
+        return fail(LGC_E_INVAL);
+    const int64_t ne = n_entries, e0 = first_entry, n_rows = (int64_t)row_end - row_begin, n_cols = (int64_t)col_hi - col_lo;
+    const int NB = cfg->n_bands, WPBR = cfg->waves_per_band_round, CAP = cfg->row_cap, GROUPS = cfg->groups == 2 ? 2 : 4;
+    const int SLAB = 64 * GROUPS;
+    if (ne > 0) {
+        if (workspace_bytes < lgc_sweep_dplan_workspace_bytes(ne, n_rows, n_cols, cfg)) return fail(LGC_E_WORKSPACE);
+        if (!aligned_to(workspace, 256)) return fail(LGC_E_ALIGN);
+    }
+    hipStream_t st = as_stream(stream_);
+    lgc_sweep_dplan *pl = new (std::nothrow) lgc_sweep_dplan();
+    if (!pl) return fail((int)hipErrorOutOfMemory);
+    auto bail = [&](int rc) -> lgc_sweep_dplan * {
+        delete pl;
+        return fail(rc);
+    };
+    try {
+        pl->cfg = *cfg;
+        pl->row_begin = row_begin;
+        const DplanWs ws = dplan_carve(workspace, ne, n_rows, n_cols, *cfg);
+        std::vector<int32_t> run_len((size_t)n_rows * NB, 0);
+        if (ne > 0) {
+            // A. histogram of the columns -> band bounds
+            hipError_t err = hipMemsetAsync(ws.hist, 0, (size_t)n_cols * 4, st);
+            if (err == hipSuccess) err = hipMemsetAsync(ws.run_len, 0, (size_t)n_rows * NB * 4, st);
+            if (err == hipSuccess) err = hipMemsetAsync(ws.bad, 0, 4, st);
+            if (err != hipSuccess) return bail((int)err);
+            const int eb = ceil_div(ne, kBlock);
+            hipLaunchKernelGGL(k_dp_hist, dim3(eb), dim3(kBlock), 0, st, entries, e0, ne, col_lo, (int32_t)n_cols, ws.hist, ws.bad);
+            std::vector<int32_t> hist((size_t)n_cols);
+            int32_t bad = 0;
+            err = hipMemcpyAsync(hist.data(), ws.hist, (size_t)n_cols * 4, hipMemcpyDeviceToHost, st);
+            if (err == hipSuccess) err = hipMemcpyAsync(&bad, ws.bad, 4, hipMemcpyDeviceToHost, st);
+            // B meanwhile: rows sorted by column
+            hipLaunchKernelGGL(k_dp_row_keys, dim3(eb), dim3(kBlock), 0, st, rowptr, row_begin, (int32_t)n_rows, entries, e0, ne,
+                               ws.keys_a, ws.idx_a);
+            size_t cb = ws.cub_bytes;
+            int row_bits = 1;
+            while ((int64_t(1) << row_bits) < n_rows) ++row_bits;
+            if (err == hipSuccess)
+                err = hipcub::DeviceRadixSort::SortPairs(ws.cub, cb, ws.keys_a, ws.keys_b, ws.idx_a, ws.idx_b, (int)ne, 0,
+                                                         24 + row_bits, st);
+            if (err == hipSuccess) err = hipStreamSynchronize(st);
+            if (err != hipSuccess) return bail((int)err);
+            if (bad) return bail(LGC_E_INVAL);                     // a column outside [col_lo, col_hi)
+            DpBounds bound;
+            for (int b = 0; b <= NB; ++b) bound.b[b] = col_hi;
+            bound.b[0] = col_lo;
+            {
+                int64_t run = 0;
+                int b = 1;
+                for (int32_t c = 0; c < n_cols && b < NB; ++c) {
+                    run += hist[(size_t)c];
+                    while (b < NB && run * NB >= ne * b) bound.b[b++] = col_lo + c + 1;
+                }
+            }
+            hipLaunchKernelGGL(k_dp_gather, dim3(eb), dim3(kBlock), 0, st, entries, e0, ne, ws.keys_b, ws.idx_b, bound, NB, ws.sorted,
+                               ws.run_len);
+            err = hipMemcpyAsync(run_len.data(), ws.run_len, run_len.size() * 4, hipMemcpyDeviceToHost, st);
+            if (err == hipSuccess) err = hipStreamSynchronize(st);
+            if (err != hipSuccess) return bail((int)err);
+        }
+        // pieces, rounds, deal: on the host, from the run lengths alone
+        PlanPieces pp;
+        const int rc = plan_pieces_and_deal(run_len, n_rows, row_begin, *cfg, pp);
+        if (rc != 0) return bail(rc);
+        if (pp.PCAP > 256) return bail(LGC_E_RANGE);
+        const int64_t n_waves = pp.n_waves, n_pieces = (int64_t)pp.pieces.size();
+        if (n_pieces > dplan_max_pieces(ne, n_rows, *cfg) || n_waves > dplan_max_waves(ne, n_rows, *cfg)) return bail(LGC_E_WORKSPACE);
+        pl->multi = pp.multi;
+        pl->wave_npieces.assign((size_t)n_waves, 0);
+        pl->piece_slot.assign((size_t)n_waves * CAP, 0);
+        pl->wave_item_ptr.assign((size_t)n_waves + 1, 0);
+        std::vector<DpPiece> table((size_t)n_pieces);
+        for (int64_t w = 0; w < n_waves; ++w) {
+            const auto &wp = pp.wave_pieces[(size_t)w];
+            pl->wave_npieces[(size_t)w] = (int32_t)wp.size();
+            int32_t items = 0;
+            for (size_t lp = 0; lp < wp.size(); ++lp) {
+                const SweepPiece &pc = pp.pieces[(size_t)wp[lp]];
+                pl->piece_slot[(size_t)w * CAP + lp] = wp[lp];
+                table[(size_t)wp[lp]] = DpPiece{pc.begin, pc.count, (int32_t)w, (int32_t)lp};
+                items += pc.count;
+            }
+            pl->wave_item_ptr[(size_t)w + 1] = pl->wave_item_ptr[(size_t)w] + items;
+        }
+        std::vector<int32_t> steps((size_t)n_waves, 0), pads((size_t)n_waves, 0);
+        if (ne > 0 && n_waves > 0) {
+            hipError_t err = hipMemcpyAsync(ws.pieces, table.data(), table.size() * sizeof(DpPiece), hipMemcpyHostToDevice, st);
+            if (err == hipSuccess)
+                err = hipMemcpyAsync(ws.item_ptr, pl->wave_item_ptr.data(), pl->wave_item_ptr.size() * 4, hipMemcpyHostToDevice, st);
+            if (err != hipSuccess) return bail((int)err);
+            const int serp = cfg->round_order == 2 ? 1 : 0;
+            hipLaunchKernelGGL(k_dp_item_keys, dim3(ceil_div(n_pieces, kBlock)), dim3(kBlock), 0, st, ws.pieces, n_pieces, ws.sorted,
+                               WPBR, NB, serp, ws.keys_a, ws.idx_a);
+            size_t cb = ws.cub_bytes;
+            int wave_bits = 1;
+            while ((int64_t(1) << wave_bits) < n_waves) ++wave_bits;
+            err = hipcub::DeviceRadixSort::SortPairs(ws.cub, cb, ws.keys_a, ws.keys_b, ws.idx_a, ws.idx_b, (int)ne, 0, 40 + wave_bits, st);
+            if (err != hipSuccess) return bail((int)err);
+            const uint32_t pad_x = 0x00FFFFFFu | ((uint32_t)CAP << 24);
+            hipLaunchKernelGGL((k_dp_steps<false>), dim3(ceil_div(n_waves, kBlock / kWave)), dim3(kBlock), 0, st, ws.keys_b, ws.idx_b,
+                               ws.sorted, ws.item_ptr, (int32_t)n_waves, GROUPS, cfg->lookahead, WPBR, NB, serp, pad_x, ws.steps, ws.pad,
+                               (const int32_t *)nullptr, (uint32_t *)nullptr);
+            err = hipMemcpyAsync(steps.data(), ws.steps, steps.size() * 4, hipMemcpyDeviceToHost, st);
+            if (err == hipSuccess) err = hipMemcpyAsync(pads.data(), ws.pad, pads.size() * 4, hipMemcpyDeviceToHost, st);
+            if (err == hipSuccess) err = hipStreamSynchronize(st);
+            if (err != hipSuccess) return bail((int)err);
+        }
+        pl->wave_slab_ptr.assign((size_t)n_waves + 1, 0);
+        int64_t n_slabs = 0, n_steps = 0, n_pad = 0;
+        for (int64_t w = 0; w < n_waves; ++w) {
+            pl->wave_slab_ptr[(size_t)w] = (int32_t)n_slabs;
+            n_slabs += (steps[(size_t)w] + 31) / 32;
+            n_steps += steps[(size_t)w];
+            n_pad += pads[(size_t)w];
+        }
+        if (n_slabs >= INT32_MAX) return bail(LGC_E_RANGE);
+        pl->wave_slab_ptr[(size_t)n_waves] = (int32_t)n_slabs;
+        pl->keys = ws.keys_b;
+        pl->idx = ws.idx_b;
+        pl->sorted = ws.sorted;
+        pl->d_item_ptr = ws.item_ptr;
+        pl->d_slab_ptr = ws.slab_ptr;
+        pl->dims.n_bands = NB;
+        pl->dims.rounds = pp.rounds;
+        pl->dims.row_cap = CAP;
+        pl->dims.piece_cap = pp.PCAP;
+        pl->dims.n_waves = n_waves;
+        pl->dims.n_slabs = n_slabs;
+        pl->dims.groups = GROUPS;
+        pl->dims.n_slots = n_pieces;
+        pl->dims.n_rows = (int32_t)n_rows;
+        pl->dims.n_entries = ne;
+        pl->dims.n_steps = n_steps;
+        pl->dims.n_padding = n_pad;
+        (void)SLAB;
+    } catch (const std::bad_alloc &) {
+        return bail((int)hipErrorOutOfMemory);
+    }
+    if (code) *code = 0;
+    return pl;
+}
+
+int lgc_sweep_dplan_dims(const lgc_sweep_dplan *plan, lgc_sweep_dims *dims) {
+    if (!plan || !dims) return LGC_E_INVAL;
+    *dims = plan->dims;
+    return 0;
+}
+
+int lgc_sweep_dplan_export_multi(const lgc_sweep_dplan *plan, lgc_multi_row *multi) {
+    if (!plan || !multi) return LGC_E_INVAL;
+    std::copy(plan->multi.begin(), plan->multi.end(), multi);
+    return 0;
+}
+
+int lgc_sweep_dplan_fill(const lgc_sweep_dplan *plan, uint32_t *slabs, int32_t *wave_slab_ptr, int32_t *wave_npieces,
+                         int32_t *piece_slot, void *stream_) {
+    if (!plan || !slabs || !wave_slab_ptr || !wave_npieces || !piece_slot) return LGC_E_INVAL;
+    hipStream_t st = as_stream(stream_);
+    auto up = [&](void *dst, const void *src, size_t bytes) -> int {
+        return bytes == 0 ? 0 : (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+    };
+    int rc = up(wave_slab_ptr, plan->wave_slab_ptr.data(), plan->wave_slab_ptr.size() * 4);
+    if (rc == 0) rc = up(wave_npieces, plan->wave_npieces.data(), plan->wave_npieces.size() * 4);
+    if (rc == 0) rc = up(piece_slot, plan->piece_slot.data(), plan->piece_slot.size() * 4);
+    if (rc != 0) return rc;
+    const lgc_sweep_cfg &cfg = plan->cfg;
+    const int64_t n_waves = plan->dims.n_waves;
+    if (n_waves > 0 && plan->dims.n_entries > 0) {
+        const uint32_t pad_x = 0x00FFFFFFu | ((uint32_t)cfg.row_cap << 24);
+        hipLaunchKernelGGL((k_dp_steps<true>), dim3(ceil_div(n_waves, kBlock / kWave)), dim3(kBlock), 0, st, plan->keys, plan->idx,
+                           plan->sorted, plan->d_item_ptr, (int32_t)n_waves, plan->dims.groups, cfg.lookahead,
+                           cfg.waves_per_band_round, cfg.n_bands, cfg.round_order == 2 ? 1 : 0, pad_x, (int32_t *)nullptr,
+                           (int32_t *)nullptr, (const int32_t *)wave_slab_ptr, slabs);
+    }
+    rc = (int)hipGetLastError();
+    if (rc != 0) return rc;
+    return (int)hipStreamSynchronize(st);        // the workspace may be released as soon as this returns
+}
+
+void lgc_sweep_dplan_free(lgc_sweep_dplan *plan) { delete plan; }
 
 // 61..64 columns: four table rows per gather instruction.  68..96: two (k_sweep_wide, 96-float accumulators, more rounds).
 // 97..128: the four-row plan again, run twice -- columns [0, 64) and [64, dim) -- into one partial table; measured against

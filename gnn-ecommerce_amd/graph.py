@@ -360,6 +360,59 @@ def sweep_plan_device(rowptr: Tensor, entries: Tensor, row_begin: int, row_end: 
     return dims, arrays
 
 
+def sweep_plan_on_device(rowptr: Tensor, entries: Tensor, row_begin: int, row_end: int, col_lo: int, col_hi: int,
+                         cfg: Optional[dict] = None) -> Optional[Tuple[dict, Dict[str, Tensor]]]:
+    """The plan built by the DEVICE planner (lgc_sweep_dplan_*: the entries never leave the device, the slabs are written
+    there; on the host only the piece list and the deal) -- the same arrays as ``sweep_plan_host``, bit for bit.  Returns
+    None when the configuration is outside what the device planner takes (piece_cap > 64, lookahead > 64)."""
+    import ctypes
+    import time
+    lib = _native.load()
+    dev = rowptr.device
+    cfg = dict(SWEEP_CFG, **(cfg or {}))
+    t0 = time.perf_counter()
+    e0, e1 = int(rowptr[row_begin]), int(rowptr[row_end])
+    c_cfg = _native.SweepCfg(**cfg)
+    ws_bytes = lib.lgc_sweep_dplan_workspace_bytes(e1 - e0, row_end - row_begin, col_hi - col_lo, ctypes.byref(c_cfg))
+    if ws_bytes == 0:
+        return None
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    code = ctypes.c_int(0)
+    with torch.cuda.device(dev):
+        handle = lib.lgc_sweep_dplan_create(_native.ptr(rowptr), _native.ptr(entries), row_begin, row_end, e0, e1 - e0, col_lo,
+                                            col_hi, ctypes.byref(c_cfg), _native.ptr(ws), ws_bytes, _native.stream_of(dev),
+                                            ctypes.byref(code))
+    if not handle:
+        if code.value == -4:                       # LGC_E_RANGE: a configuration for the host planner
+            return None
+        _native.check(code.value or -1, "lgc_sweep_dplan_create")
+    try:
+        d = _native.SweepDims()
+        _native.check(lib.lgc_sweep_dplan_dims(handle, ctypes.byref(d)), "lgc_sweep_dplan_dims")
+        dims = {k: getattr(d, k) for k, _ in _native.SweepDims._fields_}
+        i32 = dict(dtype=torch.int32, device=dev)
+        arrays = {"slabs": torch.empty(max(d.n_slabs, 1) * 64 * d.groups, **i32),
+                  "wave_slab_ptr": torch.empty(d.n_waves + 1, **i32),
+                  "wave_npieces": torch.empty(max(d.n_waves, 1), **i32),
+                  "piece_slot": torch.empty(max(d.n_waves * d.row_cap, 1), **i32),
+                  "multi": torch.empty((max(d.n_rows, 1), 4), dtype=torch.int32)}
+        with torch.cuda.device(dev):
+            _native.check(lib.lgc_sweep_dplan_fill(handle, *(arrays[k].data_ptr() for k in
+                                                             ("slabs", "wave_slab_ptr", "wave_npieces", "piece_slot")),
+                                                   _native.stream_of(dev)), "lgc_sweep_dplan_fill")
+        _native.check(lib.lgc_sweep_dplan_export_multi(handle, arrays["multi"].data_ptr()), "lgc_sweep_dplan_export_multi")
+    finally:
+        lib.lgc_sweep_dplan_free(handle)
+    del ws
+    arrays["multi"] = arrays["multi"][:d.n_rows].contiguous()
+    if PLAN_TIMING:
+        print(f"[plan] sweep plan on the device: {time.perf_counter() - t0:.3f} s", flush=True)
+    return dims, arrays
+
+
+SWEEP_PLAN_ON_DEVICE = os.environ.get("LGCN_SWEEP_PLAN_ON_DEVICE", "1") == "1"
+
+
 class SweepPlan:
     """Device arrays of a band-sweep plan (include/lgconv_hip.h, lgc_sweep_plan_*): built once per operator half on
     the host from a host copy of its rows, uploaded, then applied with lgc_spmm_sweep."""
@@ -367,8 +420,12 @@ class SweepPlan:
     def __init__(self, rowptr: Tensor, entries: Tensor, row_begin: int, row_end: int, col_lo: int, col_hi: int,
                  cfg: Optional[dict] = None):
         dev = rowptr.device
-        plan = sweep_plan_device if rowptr.is_cuda else sweep_plan_host
-        self.dims, arrays = plan(rowptr, entries, row_begin, row_end, col_lo, col_hi, cfg)
+        got = sweep_plan_on_device(rowptr, entries, row_begin, row_end, col_lo, col_hi, cfg) \
+            if (rowptr.is_cuda and SWEEP_PLAN_ON_DEVICE) else None
+        if got is None:                                # CPU tensors, or a configuration the device planner does not take
+            plan = sweep_plan_device if rowptr.is_cuda else sweep_plan_host
+            got = plan(rowptr, entries, row_begin, row_end, col_lo, col_hi, cfg)
+        self.dims, arrays = got
         self.row_begin, self.row_end = row_begin, row_end
         self.slabs, self.wave_slab_ptr = arrays["slabs"].to(dev), arrays["wave_slab_ptr"].to(dev)
         self.wave_npieces, self.piece_slot = arrays["wave_npieces"].to(dev), arrays["piece_slot"].to(dev)

@@ -262,6 +262,31 @@ int lgc_sweep_plan_upload(const lgc_sweep_plan *plan, uint32_t *slabs, int32_t *
                           int32_t *piece_slot, void *stream);
 void lgc_sweep_plan_free(lgc_sweep_plan *plan);
 
+/* The same plan -- bit for bit -- with the bulk of the work on the device (rows [row_begin, row_end) of a CSR that is
+ * ALREADY on the device; first_entry / n_entries = rowptr[row_begin] and the entry count of the range, which the caller
+ * knows): column histogram, every row sorted by column (one radix sort), the run length of every (row, band); on the host
+ * only the piece list and the deal over the wavefronts (from the run lengths, ~2 MB); back on the device every
+ * wavefront's merged column-sorted list (a second radix sort) and the conflict-free step builder, one wavefront per list
+ * (its look-ahead window is the wavefront's 64 lanes).  The 81 MB of entries are never copied to the host and the 87 MB of
+ * slabs never from it.  Needs cfg->piece_cap <= 64 and cfg->lookahead <= 64 (LGC_E_RANGE otherwise: use the host planner).
+ *   lgc_sweep_dplan_create   everything up to the sizes (returns NULL and sets *code on error); `workspace` (device,
+ *                            >= lgc_sweep_dplan_workspace_bytes) must stay untouched until _fill has returned
+ *   lgc_sweep_dplan_dims     as lgc_sweep_plan_dims
+ *   lgc_sweep_dplan_fill     writes the four arrays into caller-provided DEVICE buffers of those sizes; synchronises
+ *   lgc_sweep_dplan_export_multi   `multi` into a HOST buffer [n_rows]; multi[].row are the CSR's own row ids
+ *   lgc_sweep_dplan_free */
+typedef struct lgc_sweep_dplan lgc_sweep_dplan;
+size_t lgc_sweep_dplan_workspace_bytes(int64_t n_entries, int64_t n_rows, int64_t n_cols, const lgc_sweep_cfg *cfg);
+lgc_sweep_dplan *lgc_sweep_dplan_create(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin, int32_t row_end,
+                                        int64_t first_entry, int64_t n_entries, int32_t col_lo, int32_t col_hi,
+                                        const lgc_sweep_cfg *cfg, void *workspace, size_t workspace_bytes, void *stream,
+                                        int *code);
+int lgc_sweep_dplan_dims(const lgc_sweep_dplan *plan, lgc_sweep_dims *dims);
+int lgc_sweep_dplan_fill(const lgc_sweep_dplan *plan, uint32_t *slabs, int32_t *wave_slab_ptr, int32_t *wave_npieces,
+                         int32_t *piece_slot, void *stream);
+int lgc_sweep_dplan_export_multi(const lgc_sweep_dplan *plan, lgc_multi_row *multi);
+void lgc_sweep_dplan_free(lgc_sweep_dplan *plan);
+
 int lgc_sweep_ok(int32_t dim, int64_t table_rows, int64_t x_stride);
 
 int lgc_spmm_sweep(const uint32_t *slabs, const int32_t *wave_slab_ptr, const int32_t *wave_npieces,

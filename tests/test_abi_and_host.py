@@ -400,6 +400,20 @@ def test_argument_errors_of_the_round4_entry_points():
     rpf = lambda **kw: lib.lgc_row_plan_fill(kw.get("rp", one), 0, kw.get("re", 4), 32, kw.get("cl", 256), kw.get("ws", two),
                                              kw.get("ch", two), two, None)
     assert rpf(rp=None) == -1 and rpf(ws=None) == -1 and rpf(ch=None) == -1 and rpf(cl=0) == -1 and rpf(re=0) == 0
+    cfg = _native.SweepCfg(n_bands=8, waves_per_band_round=256, row_cap=78, piece_cap=64, lookahead=64, groups=4, round_order=2)
+    big = _native.SweepCfg(n_bands=8, waves_per_band_round=256, row_cap=78, piece_cap=112, lookahead=64, groups=4, round_order=2)
+    assert lib.lgc_sweep_dplan_workspace_bytes(1000, 10, 500, ctypes.byref(cfg)) > 1000 * 24
+    assert lib.lgc_sweep_dplan_workspace_bytes(1000, 10, 500, ctypes.byref(big)) == 0 and lib.lgc_sweep_dplan_workspace_bytes(-1, 1, 1, ctypes.byref(cfg)) == 0
+    code = ctypes.c_int(0)
+    dp = lambda **kw: lib.lgc_sweep_dplan_create(kw.get("rp", one), one, 0, kw.get("re", 4), 0, kw.get("ne", 8), 0, kw.get("hi", 100),
+                                                 ctypes.byref(kw.get("cfg", cfg)), kw.get("ws", two), kw.get("wsb", 1 << 24), None,
+                                                 ctypes.byref(code))
+    for kw, want in ((dict(rp=None), -1), (dict(re=-1), -1), (dict(ne=-1), -1), (dict(hi=0), -1), (dict(hi=1 << 25), -1), (dict(ws=None), -1),
+                     (dict(wsb=64), -3), (dict(ws=ctypes.c_void_p(520)), -5), (dict(cfg=big), -4)):
+        assert not dp(**kw) and code.value == want, (kw, code.value)
+    assert lib.lgc_sweep_dplan_dims(None, ctypes.byref(_native.SweepDims())) == -1 and lib.lgc_sweep_dplan_fill(None, one, one, one, one, None) == -1
+    assert lib.lgc_sweep_dplan_export_multi(None, one) == -1
+    lib.lgc_sweep_dplan_free(None)
     bpr = lambda **kw: lib.lgc_bpr_loss(kw.get("s", one), None, kw.get("b", 8), kw.get("size", 8), kw.get("loss", two), kw.get("grad", two),
                                         None)
     assert bpr(loss=None) == -1 and bpr(s=None) == -1 and bpr(grad=None) == -1 and bpr(b=-1) == -1 and bpr(size=0) == -1

@@ -1327,6 +1327,59 @@ def test_device_row_plan_and_split_equal_the_index_arithmetic(device, short_max,
     assert PropGraph(overlap, None, 6).split is None
 
 
+@pytest.mark.parametrize("cfg", [dict(), dict(n_bands=2, waves_per_band_round=16), dict(n_bands=1, waves_per_band_round=32),
+                                 dict(round_order=0), dict(round_order=1), dict(lookahead=16), dict(lookahead=4, piece_cap=8),
+                                 dict(groups=2, row_cap=12), dict(row_cap=5, piece_cap=4, waves_per_band_round=4)],
+                         ids=["default", "bands2", "bands1", "same_mix", "by_weight", "look16", "look4", "wide", "many_rounds"])
+def test_device_sweep_planner_builds_the_host_planners_plan(device, cfg):
+    """lgc_sweep_dplan_* (entries sorted and scanned on the device, the step builder one wavefront per list) against
+    lgc_sweep_plan_* (host C++): every array of the plan identical, over band counts, round orders, look-ahead windows,
+    both step widths and a many-round plan; item half and user half of a small graph, and an empty row range."""
+    from gnn_ecommerce_amd import graph as G
+    g, ei, ew = small_graph(37, 3000, 140, 50000)
+    n, nu = g.num_nodes, g.n_users
+    pg = PropGraph(ei.to(device), ew.to(device), n)
+    op = pg.forward_op
+    full = {**dict(G.SWEEP_CFG, n_bands=8, waves_per_band_round=8, row_cap=20, piece_cap=16, lookahead=64), **cfg}
+    for (lo, hi), (c0, c1) in (((nu, n), (0, nu)), ((0, nu), (nu, n)), ((nu + 7, nu + 7), (0, nu))):
+        want_dims, want = G.sweep_plan_host(op.rowptr, op.entries, lo, hi, c0, c1, full)
+        got = G.sweep_plan_on_device(op.rowptr, op.entries, lo, hi, c0, c1, full)
+        assert got is not None
+        dims, arr = got
+        assert dims == want_dims, (dims, want_dims)
+        for k in ("slabs", "wave_slab_ptr", "wave_npieces", "piece_slot", "multi"):
+            a, b = arr[k].cpu(), want[k]
+            if k == "slabs":                            # (an empty plan still gets a one-element buffer)
+                a, b = a[: dims["n_slabs"] * 64 * dims["groups"]], b[: dims["n_slabs"] * 64 * dims["groups"]]
+            if k == "wave_npieces":
+                a, b = a[: dims["n_waves"]], b[: dims["n_waves"]]
+            if k == "piece_slot":                       # entries beyond a wavefront's piece count are unspecified
+                npc = want["wave_npieces"].long()
+                live = torch.arange(dims["row_cap"]).view(1, -1) < npc.view(-1, 1)
+                a, b = a.view(-1, dims["row_cap"])[live], b.view(-1, dims["row_cap"])[live]
+            assert torch.equal(a, b), (k, lo, hi)
+    assert G.sweep_plan_on_device(op.rowptr, op.entries, nu, n, 0, nu, dict(full, piece_cap=112)) is None     # host planner's
+
+
+def test_device_sweep_planner_at_full_size(device, cosmetics_graph):
+    """The two plans the bench uses (D=64: four entries per step, three rounds; D=90: two entries per step, five rounds)
+    of the full-size item half, device planner against host planner: identical arrays."""
+    from gnn_ecommerce_amd import graph as G
+    g = cosmetics_graph
+    ei, ew = g.coo(device)
+    pg = PropGraph(ei, ew, g.num_nodes)
+    op = pg.forward_op
+    for cfg in (G.SWEEP_CFG, G.SWEEP_CFG_WIDE):
+        want_dims, want = G.sweep_plan_host(op.rowptr, op.entries, g.n_users, g.num_nodes, 0, g.n_users, cfg)
+        dims, arr = G.sweep_plan_on_device(op.rowptr, op.entries, g.n_users, g.num_nodes, 0, g.n_users, cfg)
+        assert dims == want_dims
+        for k in ("slabs", "wave_slab_ptr", "wave_npieces", "multi"):
+            assert torch.equal(arr[k].cpu(), want[k]), k
+        npc = want["wave_npieces"].long()
+        live = torch.arange(dims["row_cap"]).view(1, -1) < npc.view(-1, 1)
+        assert torch.equal(arr["piece_slot"].cpu().view(-1, dims["row_cap"])[live], want["piece_slot"].view(-1, dims["row_cap"])[live])
+
+
 def test_invalidate_after_an_untracked_write_and_late_index_errors(device):
     """ADVICE r1: (1) writes that bypass the version counter are invisible to the caches until invalidate();
     (2) an out-of-range label index surfaces as IndexError at the NEXT scoring call without any added sync."""
