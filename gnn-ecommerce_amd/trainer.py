@@ -66,9 +66,15 @@ class PartitionedTrainer:
         self.t = 0
         self.ids = torch.zeros((3, self.batch), dtype=torch.int64, device=dev)       # users | pos | neg of the current batch
         self.hyper = torch.zeros(6, dtype=torch.float32, device=dev)                 # lgc_adam_step_hp's scalars
-        self._hyper_host = torch.zeros(6, dtype=torch.float32)
+        # staged through a RING of pinned rows: the asynchronous copy of step t reads its row when the stream gets there, so
+        # the host may not overwrite it before -- a row is reused only after the copy that read it has completed
+        self._ring = 32
+        self._hyper_host = torch.zeros((self._ring, 6), dtype=torch.float32)
+        self._hyper_done = [None] * self._ring
         if dev.type == "cuda":
             self._hyper_host = self._hyper_host.pin_memory()
+        if pp.u1 <= pp.u0:
+            raise ValueError("this rank owns no user rows: a partition with more ranks than users cannot train")
         self.stats = torch.zeros(3, dtype=torch.float32, device=dev)
         self.use_graphs = bool(graphs) and dev.type == "cuda"
         self.warmup = int(warmup)
@@ -99,11 +105,18 @@ class PartitionedTrainer:
     def _refresh_hyper(self) -> None:
         self.t += 1
         b1, b2 = self.betas
-        h = self._hyper_host
+        slot = self.t % self._ring
+        if self._hyper_done[slot] is not None:
+            self._hyper_done[slot].synchronize()       # the copy that last read this row (32 steps ago) has completed
+        h = self._hyper_host[slot]
         h[0], h[1], h[2], h[3] = 1.0 - b1, b2, 1.0 - b2, self.eps
         h[4] = self.lr / (1.0 - b1 ** self.t)
         h[5] = math.sqrt(1.0 - b2 ** self.t)
         self.hyper.copy_(h, non_blocking=True)
+        if self.hyper.is_cuda:
+            ev = self._hyper_done[slot] or torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.hyper.device))
+            self._hyper_done[slot] = ev
 
     # -- recording ------------------------------------------------------------------------------------------------
     def _cut(self, action):
