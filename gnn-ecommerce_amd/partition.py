@@ -355,6 +355,17 @@ def own_pairs(pp: PartitionedPropagator, edge_label_index: Tensor) -> Tensor:
 SEEDED_STEP = os.environ.get("LGCN_PARTITION_SEEDED", "1") == "1"
 
 
+def check_batch(w: Tensor, users: Tensor, pos: Tensor, neg: Tensor) -> None:
+    """The kernels take the ids as raw int64 device pointers: anything else is refused here (upstream's own gathers --
+    ``init_embed[batch_usr]``, src/utils_v2.py:205-207 -- are what raises for ids outside the table; here such a pair scores
+    NaN and ``check_index_status()`` reports it)."""
+    for name, t in (("users", users), ("pos", pos), ("neg", neg)):
+        if not torch.is_tensor(t) or t.dtype != torch.int64 or t.dim() != 1 or t.device != w.device:
+            raise TypeError(f"{name} must be a 1-D int64 tensor on {w.device}")
+    if not (users.numel() == pos.numel() == neg.numel()) or users.numel() == 0:
+        raise ValueError("users, pos and neg must hold the same, non-zero number of ids")
+
+
 def step_forward(pp: "PartitionedPropagator", w: Tensor, alphas: tuple, users: Tensor, pos: Tensor, neg: Tensor, decay: float):
     """Forward half of one rank's training step on a global batch (see _PartitionedStep): returns
     (local loss, local bpr, regulariser of own users, regulariser of the batch's items, what the backward half needs)."""
@@ -446,6 +457,7 @@ def partitioned_bpr_loss(pp: PartitionedPropagator, weight: Tensor, alphas: Sequ
     user rows other ranks own unwritten in ``weight.grad`` (a caller that updates only ``pp.owned_row_ranges()``, like
     ``optim.Adam(row_ranges=...)``, never reads them).  Otherwise the dense path below.
     """
+    check_batch(weight, users, pos, neg)
     size = users.numel()
     from . import propagate
     seeded = (SEEDED_STEP and propagate.SPARSE_BACKWARD and pair_scores is None and hasattr(pp.ops, "seed_pull")

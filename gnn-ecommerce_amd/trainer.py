@@ -19,7 +19,7 @@ import torch
 from torch import Tensor
 
 from . import _native
-from .partition import Comm, PartitionedPropagator, step_backward, step_forward
+from .partition import Comm, PartitionedPropagator, check_batch, step_backward, step_forward
 
 
 class _RecordingComm(Comm):
@@ -194,7 +194,8 @@ class PartitionedTrainer:
 
     # -- public ---------------------------------------------------------------------------------------------------
     def step(self, users: Tensor, pos: Tensor, neg: Tensor) -> Tensor:
-        if users.numel() != self.batch or pos.numel() != self.batch or neg.numel() != self.batch:
+        check_batch(self.w, users, pos, neg)
+        if users.numel() != self.batch:
             raise ValueError(f"this trainer was built for batches of {self.batch} triples")
         self.ids[0].copy_(users, non_blocking=True)
         self.ids[1].copy_(pos, non_blocking=True)
