@@ -149,7 +149,9 @@ int lgc_build_tiles(const int32_t *rowptr, const lgc_entry *entries, const int32
  * into sorted_rows (int32 [n_rows]) and counts the classes (class_count uint64 [4], device).  lgc_tile_pack turns one
  * class's slice of sorted_rows into `order` (int32 [n_tiles * R], -1 padded; inside a tile the longest rows first, rank
  * rho in slot (rho % 4) * R / 4 + rho / 4) and `meta` (int32 [n_tiles], byte bt = longest row of batch bt), n_tiles =
- * ceil(n_rows / R), R = 16 (width 8) or 8.  table_rows bounds the column ids; workspace >= the _workspace_bytes answer. */
+ * ceil(n_rows / R), R = 16 (width 8) or 8.  table_rows bounds the column ids; workspace >= the _workspace_bytes answer.
+ * One-time planning calls, not hop launches: with `cold`, lgc_tile_classes reads the entry range of the rows back and
+ * synchronises `stream` once (like lgc_sweep_plan_upload, lgc_sweep_dplan_create and lgc_sweep_dplan_fill, which say so). */
 size_t lgc_tile_classes_workspace_bytes(int64_t n_rows, int64_t table_rows);
 int lgc_tile_classes(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin, int32_t row_end, int32_t max_len,
                      int32_t cold, int64_t table_rows, void *workspace, size_t workspace_bytes, int32_t *sorted_rows,
