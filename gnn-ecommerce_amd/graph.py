@@ -45,6 +45,7 @@ TILE_ORDER = os.environ.get("LGCN_TILE_ORDER", "cold")
 USE_SWEEP = os.environ.get("LGCN_SWEEP", "auto")
 SWEEP_MIN_ENTRIES = int(os.environ.get("LGCN_SWEEP_MIN_ENTRIES", "1000000"))
 SWEEP_ADAPTIVE_BANDS = os.environ.get("LGCN_SWEEP_ADAPTIVE_BANDS", "1") == "1"
+SWEEP_PIECE_ENTRIES = int(os.environ.get("LGCN_SWEEP_PIECE_ENTRIES", "20"))
 # 8 wavefronts per CU with 78 accumulators each beat 16 x 39 (44 % vs 20 % L2 hits on the item step: fewer, longer
 # lists keep the wavefronts of a band closer together); 160 KiB of LDS per CU either way.
 SWEEP_CFG = dict(n_bands=int(os.environ.get("LGCN_SWEEP_BANDS", "8")), waves_per_band_round=int(os.environ.get("LGCN_SWEEP_WAVES", "256")),
@@ -489,11 +490,14 @@ class Operator:
             # a piece (row x band) should hold ~10 entries or its LDS zero-fill / write-out / combine outweigh the
             # reuse it buys: measured on slices of the item half, 5.1 M entries (93 per row): 325 vs 346 us with the
             # sweep, 2.5 M (46 per row): 208 vs 193, 1.3 M: 134 vs 112
-            # Fewer bands for a thinner slice (a rank's item rows at world 4 / 8 hold 1/4, 1/8 of each row's entries): the
-            # most bands -- up to one per XCD -- that still leave ~10 entries per piece; a band then spans 8 / bands XCDs
-            # (block % bands) and the waves per band and round grow so that a round still fills the chip.
+            # Fewer bands for a thinner slice (a rank's item rows at world 2 / 4 / 8 hold 1/2, 1/4, 1/8 of each row's entries):
+            # the most bands -- up to one per XCD, at least two -- that still leave SWEEP_PIECE_ENTRIES (20) entries per piece;
+            # a band then spans 8 / bands XCDs (block % bands) and the waves per band and round grow so that a round still
+            # fills the chip.  Measured (profiles/r04c): one GPU (186 entries per row) 8 bands 531 us per hop, 4 bands 548;
+            # world 2 (93): 4 bands 296, 8 bands 307; world 4 (46): 2 bands 167, 4 bands 173; world 8 (23): 2 bands 105.5,
+            # 1 band 108.5, 4 bands 112.6 -- i.e. ~23 entries per piece wins everywhere, but never fewer than two bands.
             bands = SWEEP_CFG["n_bands"]
-            while SWEEP_ADAPTIVE_BANDS and bands > 2 and n_ent < 10 * bands * n_rows:
+            while SWEEP_ADAPTIVE_BANDS and bands > 2 and n_ent < SWEEP_PIECE_ENTRIES * bands * n_rows:
                 bands //= 2
             dense_enough = n_ent >= max(SWEEP_MIN_ENTRIES, 10 * bands * n_rows)
             if long_rows and (USE_SWEEP == "1" or (dense_enough and n_cols >= 1 << 17)):
