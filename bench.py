@@ -197,13 +197,14 @@ def rank_local_bench(graph, ei, ew, dim, layers, world, ranks, single_hop_s):
             torch.cuda.synchronize()
             reps = 20
             times = []
-            for _ in range(reps):                   # each forward timed on its own: the MEDIAN is reported -- one allocator
-                t0 = time.perf_counter()            # stall (a fresh 434 MB block: tens of ms) in a 20-forward loop otherwise
-                pp.propagate_sum(x0, alphas)        # shows up as +400 us per hop (seen once in four runs)
+            for _ in range(5):                      # five batches of ten back-to-back forwards (like the headline's timed
+                t0 = time.perf_counter()            # loop), the MEDIAN batch is reported: one allocator stall (a fresh
+                for _ in range(10):                 # 434 MB block: tens of ms) otherwise shows up as +400 us per hop
+                    pp.propagate_sum(x0, alphas)    # (seen once in four runs)
                 torch.cuda.synchronize()
-                times.append(time.perf_counter() - t0)
+                times.append((time.perf_counter() - t0) / 10)
             hop_us.append(statistics.median(times) / layers * 1e6)
-            hop_mean_us.append(sum(times) / reps / layers * 1e6)
+            hop_mean_us.append(sum(times) / len(times) / layers * 1e6)
             w = torch.nn.Parameter(x0.clone())
             opt = HipAdam([w], 0.005, row_ranges=pp.owned_row_ranges())
             gen = torch.Generator().manual_seed(SEED)
@@ -248,7 +249,8 @@ def rank_local_bench(graph, ei, ew, dim, layers, world, ranks, single_hop_s):
                 "us_per_hop_mean_by_rank": hop_mean_us, "ceiling_x": single_hop_s * 1e6 / worst,
                 "train_ms_per_step": max(train_graph_ms), "train_ms_per_step_autograd": max(train_ms),
                 "what": "local work of one rank per hop / per training step on this one GPU, every all-reduce stubbed out; "
-                        "medians of 20 individually timed forwards / steps (means beside them); ceiling_x = this run's "
+                        "us_per_hop: median of five batches of ten back-to-back forwards (mean beside it); training: medians of 20 "
+                        "individually timed steps; ceiling_x = this run's "
                         "single-GPU hop time / us_per_hop (no exchange cost in it); train_ms_per_step = "
                         "trainer.PartitionedTrainer with the step recorded as HIP graphs between the collectives, "
                         "train_ms_per_step_autograd = partitioned_bpr_loss + backward() + optim.Adam(row_ranges)"}
