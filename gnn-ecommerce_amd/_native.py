@@ -17,7 +17,7 @@ import torch
 LIB_NAME = "liblgconv_hip.so"
 # LGCN_LIB_PATH selects another build of the SAME library (A/B kernel experiments); never a fallback.
 LIB_PATH = os.environ.get("LGCN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", LIB_NAME)
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 # status bits (include/lgconv_hip.h)
 ST_INDEX_OOB = 1
@@ -73,6 +73,9 @@ SIGNATURES = {
                          c_int32, c_void_p]),
     "lgc_spmm_rows": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                               c_void_p, c_int64, c_float, c_float, c_int32, c_void_p]),
+    "lgc_spmm_rows_split": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p,
+                                    c_int64, c_int64, c_void_p, c_int64, c_float, c_float, c_int32, c_int32, c_void_p, c_void_p,
+                                    c_int64, c_void_p]),
     "lgc_bipartite_split": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "lgc_row_plan_workspace_bytes": (c_size_t, [c_int64]),
     "lgc_row_plan_count": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_void_p]),

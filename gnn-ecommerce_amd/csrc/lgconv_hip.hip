@@ -487,12 +487,8 @@ __global__ __launch_bounds__(kBlock) void k_seed_pull_chunks(SpmmArgs p, const l
 // Rows of up to 32 entries are summed by lane group 0 in entry order -- the same association, hence the same bits, as the
 // tiled kernels and the row-pointer kernel; longer rows are strided over the lane groups and reduced in group order.
 template <int VEC>
-__global__ __launch_bounds__(kBlock) void k_spmm_rows(SpmmArgs p, const int64_t *__restrict__ row_ids, int64_t n_ids) {
+__device__ __forceinline__ void listed_row_body(const SpmmArgs &p, const int64_t row) {
     const int lane = threadIdx.x & (kWave - 1);
-    const int64_t m = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x / kWave);
-    if (m >= n_ids) return;  // wave-uniform
-    const int64_t row = row_ids[m];
-    if (row < p.row_begin || row >= p.row_end) return;   // not a row of this operator half: skipped
     const int groups = kWave / p.lpr;
     const int g = lane / p.lpr;
     const int l = lane - g * p.lpr;
@@ -540,6 +536,135 @@ __global__ __launch_bounds__(kBlock) void k_spmm_rows(SpmmArgs p, const int64_t 
     finish_row<VEC, SpmmArgs>(p, row, c0, acc, rv);
 }
 
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_spmm_rows(SpmmArgs p, const int64_t *__restrict__ row_ids, int64_t n_ids) {
+    const int64_t m = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x / kWave);
+    if (m >= n_ids) return;  // wave-uniform
+    const int64_t row = row_ids[m];
+    if (row < p.row_begin || row >= p.row_end) return;   // not a row of this operator half: skipped
+    listed_row_body<VEC>(p, row);
+}
+
+// Listed rows of ANY length (lgc_spmm_rows_split).  The rows a training step scores on the item side are item rows: 186
+// entries on average, the hubs beyond 10^5 -- one wavefront per row would leave the step waiting for the wavefront that
+// walks a hub.  The list is therefore cut into chunks ON THE DEVICE (no host round trip, fixed launch shapes, so the
+// step can be recorded as a HIP graph): k_rows_plan (ONE workgroup) counts the entries of the listed rows, picks the
+// chunk length -- kRowsChunk, or longer if the caller's partial table would not hold that many chunks -- and writes every
+// list position's first chunk number (an exclusive scan; a row of up to 32 entries, or an empty one, is one chunk; a
+// position whose id lies outside the operator half has none); k_rows_chunks: a fixed grid of wavefronts strides over the
+// chunk numbers, finds the list position that owns a chunk (a 64-ary search: the lanes probe 64 offsets at once) and
+// either finishes the row (one chunk: rows of up to 32 entries in entry order, the bits of the tiled kernels) or leaves
+// a partial row; k_rows_combine adds the partial rows of a position in chunk order and applies the epilogue.  A repeated
+// id is computed once per occurrence and written with the same bits.
+constexpr int kRowsPlanBlock = 1024;
+constexpr int kRowsChunk = 256;
+
+__global__ __launch_bounds__(kRowsPlanBlock) void k_rows_plan(const int32_t *__restrict__ rowptr, const int64_t *__restrict__ row_ids,
+                                                              int64_t n_ids, int32_t row_begin, int32_t row_end, int64_t cap,
+                                                              int32_t *__restrict__ work) {
+    constexpr int kWaves = kRowsPlanBlock / kWave;
+    __shared__ long long s_sum[kWaves];
+    __shared__ int s_scan[kWaves];
+    __shared__ int s_len, s_tile;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+    long long sum = 0;
+    for (int64_t m = tid; m < n_ids; m += kRowsPlanBlock) {
+        const int64_t row = row_ids[m];
+        if (row >= row_begin && row < row_end) sum += rowptr[row + 1] - rowptr[row];
+    }
+    for (int off = kWave / 2; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+    if (lane == 0) s_sum[wv] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        long long total = 0;
+        for (int i = 0; i < kWaves; ++i) total += s_sum[i];
+        // sum_i ceil(len_i / L) <= total / L + n_ids  must fit the partial table: L >= total / (cap - n_ids)
+        const long long room = cap - n_ids;          // >= 1 (checked by the host)
+        long long len = kRowsChunk;
+        if (total / kRowsChunk > room) len = ((total + room - 1) / room + kWave - 1) / kWave * kWave;
+        s_len = (int)(len > 0x40000000 ? 0x40000000 : len);
+    }
+    __syncthreads();
+    const int chunk_len = s_len;
+    int base = 0;
+    for (int64_t m0 = 0; m0 < n_ids; m0 += kRowsPlanBlock) {
+        const int64_t m = m0 + tid;
+        int c = 0;
+        if (m < n_ids) {
+            const int64_t row = row_ids[m];
+            if (row >= row_begin && row < row_end) {
+                const int len = rowptr[row + 1] - rowptr[row];
+                c = len <= 32 ? 1 : (len + chunk_len - 1) / chunk_len;
+            }
+        }
+        int incl = c;
+        for (int off = 1; off < kWave; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (lane == kWave - 1) s_scan[wv] = incl;
+        __syncthreads();
+        if (wv == 0) {
+            const int v = lane < kWaves ? s_scan[lane] : 0;
+            int iv = v;
+            for (int off = 1; off < kWaves; off <<= 1) {
+                const int t = __shfl_up(iv, off);
+                if (lane >= off) iv += t;
+            }
+            if (lane < kWaves) s_scan[lane] = iv - v;
+            if (lane == kWaves - 1) s_tile = iv;
+        }
+        __syncthreads();
+        if (m < n_ids) work[m] = base + s_scan[wv] + incl - c;
+        base += s_tile;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        work[n_ids] = base;
+        work[n_ids + 1] = chunk_len;
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_rows_chunks(SpmmArgs p, const int64_t *__restrict__ row_ids, int64_t n_ids,
+                                                       const int32_t *__restrict__ work, float *__restrict__ partials,
+                                                       int32_t compact) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t n_waves = (int64_t)gridDim.x * (kBlock / kWave);
+    const int32_t total = work[n_ids], chunk_len = work[n_ids + 1];
+    for (int64_t w = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x / kWave); w < total; w += n_waves) {   // wave-uniform
+        // the last list position m with work[m] <= w (then w < work[m + 1]: that position owns chunk w); invariant
+        // work[lo] <= w < work[hi], the lanes probe the range at 64 evenly spaced offsets per round
+        int64_t lo = 0, hi = n_ids;
+        while (hi - lo > 1) {
+            const int64_t step = (hi - lo + kWave - 1) / kWave;
+            const int64_t at = lo + (int64_t)lane * step;
+            const bool le = at < hi && work[at] <= (int32_t)w;
+            const int k = __popcll(__ballot(le)) - 1;            // lane 0 probes lo itself: at least one bit
+            lo += (int64_t)k * step;
+            hi = min(lo + step, hi);
+        }
+        const int64_t m = lo;
+        const int64_t row = row_ids[m];
+        const int32_t first = work[m], count = work[m + 1] - first;
+        const int32_t s = p.rowptr[row], e = p.rowptr[row + 1];
+        SpmmArgs q = p;
+        if (compact) q.y = p.y + (m - row) * p.y_stride;          // y[row] of q is y[m] of p
+        if (count == 1) {
+            if (e - s <= 32) {
+                listed_row_body<VEC>(q, row);
+            } else {
+                const lgc_chunk ch = {(int32_t)row, s, e, -1};
+                chunk_core<VEC>(q, ch, partials);
+            }
+        } else {
+            const int32_t begin = s + (int32_t)(w - first) * chunk_len;
+            const lgc_chunk ch = {(int32_t)row, begin, min(begin + chunk_len, e), (int32_t)w};
+            chunk_core<VEC>(q, ch, partials);
+        }
+    }
+}
+
 // One launch per operator and hop: the first `chunk_blocks` workgroups take the chunk work list (long rows
 // are dispatched first, they run longest), the rest the short rows.  Launching the two parts separately
 // left each one's ramp-up and tail exposed -- 7 back-to-back launches per hop of 4-45 us each on a rank of
@@ -561,12 +686,8 @@ __global__ __launch_bounds__(kBlock) void k_spmm_hop(SpmmArgs p, const lgc_chunk
 // (4 loads in flight per group), then the G group sums are added in group order -- a fixed
 // association, so the result does not depend on scheduling.
 template <int VEC>
-__global__ __launch_bounds__(kBlock) void k_spmm_combine(SpmmArgs p, const lgc_multi_row *__restrict__ multi,
-                                                        int32_t n_multi, const float *__restrict__ partials) {
+__device__ __forceinline__ void combine_core(const SpmmArgs &p, const lgc_multi_row mr, const float *__restrict__ partials) {
     const int lane = threadIdx.x & (kWave - 1);
-    const int64_t m = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x / kWave);
-    if (m >= n_multi) return;  // wave-uniform
-    const lgc_multi_row mr = multi[m];
     const int groups = kWave / p.lpr;
     const int g = lane / p.lpr;
     const int l = lane - g * p.lpr;
@@ -605,6 +726,30 @@ __global__ __launch_bounds__(kBlock) void k_spmm_combine(SpmmArgs p, const lgc_m
         if (p.r != nullptr) rv = load_row<VEC>(p.r + (int64_t)mr.row * p.r_stride + c0);
         finish_row<VEC, SpmmArgs>(p, mr.row, c0, acc, rv);
     }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_spmm_combine(SpmmArgs p, const lgc_multi_row *__restrict__ multi,
+                                                        int32_t n_multi, const float *__restrict__ partials) {
+    const int64_t m = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x / kWave);
+    if (m >= n_multi) return;  // wave-uniform
+    combine_core<VEC>(p, multi[m], partials);
+}
+
+// lgc_spmm_rows_split, last launch: one wavefront per list position that was cut into several chunks.
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_rows_combine(SpmmArgs p, const int64_t *__restrict__ row_ids, int64_t n_ids,
+                                                        const int32_t *__restrict__ work, const float *__restrict__ partials,
+                                                        int32_t compact) {
+    const int64_t m = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x / kWave);
+    if (m >= n_ids) return;  // wave-uniform
+    const int32_t first = work[m], last = work[m + 1];
+    if (last - first <= 1) return;   // no chunk (foreign id) or finished by k_rows_chunks
+    const int64_t row = row_ids[m];
+    SpmmArgs q = p;
+    if (compact) q.y = p.y + (m - row) * p.y_stride;
+    const lgc_multi_row mr = {(int32_t)row, first, last};
+    combine_core<VEC>(q, mr, partials);
 }
 
 
@@ -2830,6 +2975,40 @@ int lgc_spmm_rows(const int32_t *rowptr, const lgc_entry *entries, int32_t row_b
         constexpr int V = decltype(vec)::value;
         hipLaunchKernelGGL((k_spmm_rows<V>), dim3(ceil_div(n_ids, kBlock / kWave)), dim3(kBlock), 0, as_stream(stream_), p, row_ids,
                            n_ids);
+        return (int)hipGetLastError();
+    });
+}
+
+int lgc_spmm_rows_split(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin, int32_t row_end, const int64_t *row_ids,
+                        int64_t n_ids, int64_t table_rows, const float *x, int64_t x_stride, float *y, int64_t y_stride, int64_t y_rows,
+                        const float *r, int64_t r_stride, float a, float b, int32_t dim, int32_t compact, int32_t *work,
+                        float *partials, int64_t partial_rows, void *stream_) {
+    DimCfg cfg;
+    if (!dim_cfg(dim, &cfg)) return LGC_E_DIM;
+    if (!rowptr || !x || !y || row_begin < 0 || row_end < row_begin || table_rows < row_end || n_ids < 0 || x == y) return LGC_E_INVAL;
+    if (x_stride < dim || y_stride < dim || (r && r_stride < dim)) return LGC_E_INVAL;
+    if (y_rows < (compact ? n_ids : (int64_t)row_end)) return LGC_E_INVAL;
+    if (!aligned_to(x, 4) || !aligned_to(y, 4) || (r && !aligned_to(r, 4))) return LGC_E_ALIGN;
+    if (n_ids == 0) return 0;
+    if (!row_ids || !entries || !work || !partials) return LGC_E_INVAL;
+    // every list position may end its row with a short chunk: at least one partial row per position and one to spare;
+    // chunk numbers are int32
+    if (partial_rows <= n_ids || partial_rows >= INT32_MAX || n_ids >= INT32_MAX - 2) return LGC_E_RANGE;
+    if (!aligned_to(partials, 4)) return LGC_E_ALIGN;
+    hipStream_t stream = as_stream(stream_);
+    SpmmArgs p{rowptr, entries, x, y, r, x_stride, y_stride, r_stride, a, b, dim, cfg.lpr, row_begin, row_end, 0, 0};
+    const int waves_per_block = kBlock / kWave;
+    return dispatch_dim(cfg, [&](auto vec) -> int {
+        constexpr int V = decltype(vec)::value;
+        hipLaunchKernelGGL(k_rows_plan, dim3(1), dim3(kRowsPlanBlock), 0, stream, rowptr, row_ids, n_ids, row_begin, row_end,
+                           partial_rows, work);
+        // a fixed grid strides over the chunk numbers (their count is known on the device only): enough wavefronts for a
+        // few thousand chunks to run side by side, every wavefront leaves the loop once the numbers run out
+        const int64_t want = ceil_div(std::min<int64_t>(partial_rows, 8192), waves_per_block);
+        hipLaunchKernelGGL((k_rows_chunks<V>), dim3((unsigned)std::max<int64_t>(want, 1)), dim3(kBlock), 0, stream, p, row_ids, n_ids,
+                           work, partials, compact);
+        hipLaunchKernelGGL((k_rows_combine<V>), dim3(ceil_div(n_ids, waves_per_block)), dim3(kBlock), 0, stream, p, row_ids, n_ids,
+                           work, partials, compact);
         return (int)hipGetLastError();
     });
 }

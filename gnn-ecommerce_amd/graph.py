@@ -612,11 +612,31 @@ class Operator:
         return out
 
 
+_rows_scratch: Dict[tuple, Tuple[Tensor, Tensor]] = {}
+ROWS_SPLIT_ROOM = 16384      # partial rows beyond one per list position: 256-entry chunks up to 4 M listed entries
+
+
+def _rows_split_scratch(device: torch.device, n_ids: int, dim: int) -> Tuple[Tensor, Tensor]:
+    """Scratch of lgc_spmm_rows_split (chunk numbers, partial rows), owned by one (device, stream, host thread) triple like
+    every other scratch buffer that lives across launches: two steps on different streams never share it."""
+    import threading
+    key = (device, torch.cuda.current_stream(device).cuda_stream, threading.get_ident(), dim)
+    got = _rows_scratch.get(key)
+    if got is None or got[0].numel() < n_ids + 2:
+        cap = max(n_ids, 4096)
+        got = (torch.empty(cap + 2, dtype=torch.int32, device=device),
+               torch.empty((cap + ROWS_SPLIT_ROOM, dim), dtype=torch.float32, device=device))
+        _rows_scratch[key] = got
+    return got
+
+
 def apply_rows(op: "Operator", rows: Tensor, x: Tensor, out: Tensor, a: float = 1.0, r: Optional[Tensor] = None,
-               b: float = 0.0) -> Tensor:
+               b: float = 0.0, split: bool = False, compact: bool = False) -> Tensor:
     """out[row] = a * (A x)[row] + b * r[row] for the rows listed in ``rows`` (int64, on the device; ids outside the
     operator's plan range are skipped, repeats are harmless); every other row of ``out`` is left untouched.
-    ``lgc_spmm_rows``: one wavefront per listed row."""
+    ``lgc_spmm_rows``: one wavefront per listed row -- right for user rows (6 entries on average).  ``split=True``
+    (``lgc_spmm_rows_split``): the listed rows are cut into chunks on the device first -- for item rows (186 entries on
+    average, hubs beyond 10^5).  ``compact=True`` (with ``split``): ``out`` is a [len(rows), D] table in list order."""
     _check_table(x, "x")
     _check_table(out, "out")
     if r is not None:
@@ -627,12 +647,28 @@ def apply_rows(op: "Operator", rows: Tensor, x: Tensor, out: Tensor, a: float = 
     dim = x.size(1)
     if out.size(1) != dim or (r is not None and r.size(1) != dim):
         raise ValueError("x, out and r must have the same width")
+    if compact and not split:
+        raise ValueError("compact output needs split=True")
     rows = rows.contiguous()
     lib = _native.load()
     p = op.plan
+    n_ids = rows.numel()
     with torch.cuda.device(x.device):
+        if split:
+            if n_ids == 0:
+                return out
+            if out.size(0) < (n_ids if compact else p.row_end):
+                raise ValueError("out has too few rows")
+            work, partials = _rows_split_scratch(x.device, n_ids, dim)
+            code = lib.lgc_spmm_rows_split(_native.ptr(op.rowptr), _native.ptr(op.entries), p.row_begin, p.row_end, _native.ptr(rows),
+                                           n_ids, x.size(0), _native.ptr(x), x.stride(0), _native.ptr(out), out.stride(0),
+                                           out.size(0), _native.ptr(r), 0 if r is None else r.stride(0), float(a), float(b), dim,
+                                           int(compact), _native.ptr(work), _native.ptr(partials), partials.size(0),
+                                           _native.stream_of(x.device))
+            _native.check(code, "lgc_spmm_rows_split")
+            return out
         code = lib.lgc_spmm_rows(_native.ptr(op.rowptr), _native.ptr(op.entries), p.row_begin, p.row_end, _native.ptr(rows),
-                                 rows.numel(), min(x.size(0), out.size(0)), _native.ptr(x), x.stride(0), _native.ptr(out),
+                                 n_ids, min(x.size(0), out.size(0)), _native.ptr(x), x.stride(0), _native.ptr(out),
                                  out.stride(0), _native.ptr(r), 0 if r is None else r.stride(0), float(a), float(b), dim,
                                  _native.stream_of(x.device))
     _native.check(code, "lgc_spmm_rows")

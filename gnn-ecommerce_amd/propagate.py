@@ -104,10 +104,12 @@ def bipartite_sum(user_op: Operator, item_op: Operator, split: int, x0: Tensor, 
     and the weighted sums over layers are taken on the small item tables only (``lgc_lincomb``, in the
     reference's own order: out = out + x * alpha).  Same K item steps + K user steps as K plain hops.
 
-    ``final_rows`` (int64 node ids on the device): the caller will only ever read these rows of the result plus the item
-    block -- a training step scores 2B label pairs (src/lightgcn.py:123-125).  The LAST user step, whose 1.6 M output rows
+    ``final_rows`` (int64 node ids on the device, users and items alike): the caller will only ever read these rows of the
+    result -- a training step scores 2B label pairs (src/lightgcn.py:123-125).  The LAST user step, whose 1.6 M output rows
     nothing else consumes, is then computed for the listed user rows only (``lgc_spmm_rows``: a few thousand gathers, the
-    same bits for rows of up to 32 entries); every other user row of the result is left uninitialised.
+    same bits for rows of up to 32 entries), and the LAST item step -- otherwise a full sweep over the user table -- for the
+    listed item rows only (``lgc_spmm_rows_split``; SCORED_ITEM_ROWS_ONLY); every other row of the result is left
+    uninitialised.
     """
     k = len(alphas) - 1
     if k == 0:
@@ -131,7 +133,20 @@ def bipartite_sum(user_op: Operator, item_op: Operator, split: int, x0: Tensor, 
                 tables.append(nxt)
             else:
                 out = torch.empty_like(x0)
-                if uniform:
+                rows_only = final_rows is not None
+                if rows_only and SCORED_ITEM_ROWS_ONLY:
+                    # the scores read the item block at the batch's item rows only: the last item step -- a full sweep over
+                    # the 420 MB user table otherwise -- is computed for the listed rows (lgc_spmm_rows_split: the rows cut
+                    # into chunks on the device), on top of rest = sum_{l<K} alpha_l x_l[items]
+                    mix = nxt
+                    _native.lincomb(mix[split:], [(alphas[l], tables[l - 1][split:]) for l in range(1, k + 1)])
+                    if all(a == alphas[0] for a in alphas):
+                        rest = mix                                              # the same table when the alphas are equal
+                    else:
+                        rest = scratch_table(x0)
+                        _native.lincomb(rest[split:], [(alphas[l], tables[l][split:]) for l in range(0, k)])
+                    apply_rows(item_op, final_rows, tables[-1], out, a=alphas[k], r=rest, b=1.0, split=True)
+                elif uniform:
                     mix = nxt                                                   # item rows: sum_l alpha_l x_{l-1}
                     _native.lincomb(mix[split:], [(alphas[l], tables[l - 1][split:]) for l in range(1, k + 1)])
                     item_op.apply(tables[-1], out, a=alphas[k], r=mix, b=1.0)   # out[items] = mix + alpha_K x_K[items]
@@ -141,7 +156,7 @@ def bipartite_sum(user_op: Operator, item_op: Operator, split: int, x0: Tensor, 
                     mix = scratch_table(x0)
                     _native.lincomb(mix[split:], [(alphas[l], tables[l - 1][split:]) for l in range(1, k + 1)])
                     _native.lincomb(out[split:], [(alphas[l], tables[l][split:]) for l in range(0, k + 1)])
-                if final_rows is None:
+                if not rows_only:
                     user_op.apply(mix, out, a=1.0, r=x0, b=alphas[0])            # out[users]
                 else:
                     apply_rows(user_op, final_rows, mix, out, a=1.0, r=x0, b=alphas[0])
@@ -159,6 +174,8 @@ def _layer_sum(graph: PropGraph, x: Tensor, alphas: tuple, transpose: bool, fina
 UNIFORM_ALPHA_SHORTCUT = {"0": False, "force": "force"}.get(os.environ.get("LGCN_UNIFORM_ALPHA_SHORTCUT", "1"), True)
 # the forward of a scoring step computes the last user step only for the rows its label pairs name (bipartite_sum)
 SCORED_ROWS_ONLY = os.environ.get("LGCN_SCORED_ROWS_ONLY", "1") == "1"
+# ... and the last ITEM step as well (lgc_spmm_rows_split); "0": the full item step, as get_embedding runs it
+SCORED_ITEM_ROWS_ONLY = os.environ.get("LGCN_SCORED_ITEM_ROWS_ONLY", "1") == "1"
 
 
 class _PropagateSum(torch.autograd.Function):
@@ -400,8 +417,8 @@ class DeviceOps:
         op.apply(x, out, a=a, r=r, b=b)
 
     def apply_rows(self, op: Operator, rows: Tensor, x: Tensor, out: Tensor, a: float = 1.0, r: Optional[Tensor] = None,
-                   b: float = 0.0) -> None:
-        apply_rows(op, rows, x, out, a=a, r=r, b=b)
+                   b: float = 0.0, split: bool = False, compact: bool = False) -> None:
+        apply_rows(op, rows, x, out, a=a, r=r, b=b, split=split, compact=compact)
 
     def lincomb(self, y: Tensor, terms) -> None:
         _native.lincomb(y, terms)

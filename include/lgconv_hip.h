@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LGC_ABI_VERSION 11
+#define LGC_ABI_VERSION 12
 
 /* argument errors (negative return values) */
 #define LGC_E_INVAL      (-1)  /* null pointer, negative size, bad flag                    */
@@ -201,6 +201,28 @@ int lgc_spmm(const int32_t *rowptr, const lgc_entry *entries,
 int lgc_spmm_rows(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin, int32_t row_end, const int64_t *row_ids,
                   int64_t n_ids, int64_t table_rows, const float *x, int64_t x_stride, float *y, int64_t y_stride, const float *r,
                   int64_t r_stride, float a, float b, int32_t dim, void *stream);
+
+/* The same for a list that names LONG rows (ABI 12).  What it is for: the scores of a training step read the propagated
+ * table at the batch's 2B item rows too (src/lightgcn.py:123-125: `out[edge_label_index[1]]`), and nothing else of the last
+ * item step's [n_items, D] block is ever read -- but an item row holds 186 entries on average and a hub beyond 10^5, which
+ * one wavefront per row cannot balance.  The listed rows are cut into chunks ON THE DEVICE (no host round trip, fixed launch
+ * shapes: the step can be recorded as a HIP graph): a one-workgroup planning launch (entries of the listed rows -> chunk
+ * length: 256 entries, or longer when `partial_rows` would not hold that many chunks -> first chunk number of every list
+ * position), a fixed grid of wavefronts striding over the chunk numbers (rows of up to 32 entries finish in entry order
+ * with the bits of lgc_spmm_tiles; longer single-chunk rows finish directly; the others leave partial rows), and one
+ * wavefront per cut position adding its partial rows in chunk order: deterministic, no float atomics.
+ *   y_rows        rows of y (compact: >= n_ids; else > every listed id of the operator half, i.e. >= row_end)
+ *   compact       0: y[row_ids[m]] is written (as lgc_spmm_rows); 1: y[m] is written -- a [n_ids, dim] table in list order
+ *                 (positions whose id lies outside [row_begin, row_end) are left untouched), e.g. the block a rank of a
+ *                 partition all-reduces instead of the whole item block
+ *   work          int32 [n_ids + 2] device scratch
+ *   partials      fp32 [partial_rows, dim] device scratch, partial_rows > n_ids (LGC_E_RANGE otherwise); n_ids + 16384
+ *                 keeps 256-entry chunks up to 4 M listed entries
+ * r (optional epilogue rows) is indexed by row id in both modes.  Three launches on `stream`. */
+int lgc_spmm_rows_split(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin, int32_t row_end,
+                        const int64_t *row_ids, int64_t n_ids, int64_t table_rows, const float *x, int64_t x_stride, float *y,
+                        int64_t y_stride, int64_t y_rows, const float *r, int64_t r_stride, float a, float b, int32_t dim,
+                        int32_t compact, int32_t *work, float *partials, int64_t partial_rows, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Band sweep: long rows over a gathered table far larger than the caches (the item step of a user|item graph).

@@ -59,14 +59,15 @@ class CpuOps:
         rows = torch.repeat_interleave(torch.arange(lo, hi), op.rowptr[lo + 1:hi + 1] - op.rowptr[lo:hi])
         return rows, op.cols[s:e], op.vals[s:e]
 
-    def apply_rows(self, op, rows, x, out, a=1.0, r=None, b=0.0):
-        """lgc_spmm_rows: the listed rows only (ids outside the operator's range skipped), the others untouched."""
-        for row in torch.unique(rows).tolist():
+    def apply_rows(self, op, rows, x, out, a=1.0, r=None, b=0.0, split=False, compact=False):
+        """lgc_spmm_rows / lgc_spmm_rows_split: the listed rows only (ids outside the operator's range skipped), the others
+        untouched; ``compact``: out[m] for list position m instead of out[row]."""
+        for m, row in enumerate(rows.tolist()):
             if not op.row_begin <= row < op.row_end:
                 continue
             s, e = int(op.rowptr[row]), int(op.rowptr[row + 1])
             acc = (op.vals[s:e].view(-1, 1) * x[op.cols[s:e]]).sum(0) if e > s else torch.zeros(x.size(1))
-            out[row] = a * acc + (b * r[row] if r is not None else 0.0)
+            out[m if compact else row] = a * acc + (b * r[row] if r is not None else 0.0)
 
     def lincomb(self, y, terms):
         acc = terms[0][1] * terms[0][0]

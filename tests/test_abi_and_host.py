@@ -355,6 +355,14 @@ def test_argument_errors_of_the_round3_entry_points():
                                           kw.get("y", two), kw.get("ys", 64), None, 0, 1.0, 0.0, kw.get("dim", 64), None)
     assert rows(dim=300) == -2 and rows(y=one) == -1 and rows(ys=32) == -1 and rows(n=-1) == -1 and rows(re=9) == -1
     assert rows(n=0) == 0
+    split = lambda **kw: lib.lgc_spmm_rows_split(one, one, 0, kw.get("re", 4), one, kw.get("n", 3), kw.get("tr", 8), one, 64,
+                                                 kw.get("y", two), kw.get("ys", 64), kw.get("yr", 8), None, 0, 1.0, 0.0,
+                                                 kw.get("dim", 64), kw.get("compact", 0), kw.get("work", one),
+                                                 kw.get("part", two), kw.get("pr", 100), None)
+    assert split(dim=300) == -2 and split(y=one) == -1 and split(ys=32) == -1 and split(n=-1) == -1 and split(re=9) == -1
+    assert split(yr=3) == -1 and split(compact=1, yr=2) == -1                      # y must hold every row that may be written
+    assert split(work=None) == -1 and split(part=None) == -1 and split(pr=3) == -4 and split(pr=2) == -4
+    assert split(n=0) == 0
     cb = _native.EXCHANGE_FN(lambda *a: 0)
     op = _native.OperatorC()
     assert lib.lgc_hop_exchange(ctypes.byref(op), ctypes.byref(op), 100, one, 64, two, 64, None, 0, 1.0, 0.0, 64, 90, 20, 1, cb,

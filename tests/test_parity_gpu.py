@@ -955,6 +955,79 @@ def test_listed_rows_hop_equals_the_full_hop(device, dim):
     assert torch.equal(out2[listed], out[listed])                          # deterministic
 
 
+@pytest.mark.parametrize("dim", [64, 90, 7, 128])
+def test_listed_long_rows_are_cut_into_chunks_on_the_device(device, dim, monkeypatch):
+    """lgc_spmm_rows_split: the hop for a list of rows of any length (the last ITEM step of a scoring forward: item rows
+    of hundreds to thousands of entries) against the full step -- 1e-6 on long rows, bit for bit on rows of up to 32
+    entries; repeats, ids of the other half and out-of-range ids are harmless; unlisted rows are not written; the compact
+    form writes list position m instead of row id; a partial table with room for 8 extra rows only (chunks of thousands of
+    entries instead of 256) gives the same sums; deterministic."""
+    from gnn_ecommerce_amd import graph as G
+    from gnn_ecommerce_amd.graph import apply_rows
+    g = synth.make_bipartite(3000, 60, 40000, seed=21)                    # item rows: 666 entries on average
+    ei, ew = g.coo(device)
+    n, nu = g.num_nodes, g.n_users
+    pg = PropGraph(ei, ew, n)
+    user_op, item_op = pg.halves()
+    x, r = synth.xavier_table(n, dim, 3, device), synth.xavier_table(n, dim, 4, device)
+    full = torch.empty_like(x)
+    item_op.apply(x, full, a=0.5, r=r, b=0.25)
+    user_op.apply(x, full, a=0.5, r=r, b=0.25)
+    gen = torch.Generator().manual_seed(2)
+    rows = torch.cat([torch.randint(0, n, (500,), generator=gen), torch.tensor([nu, nu, nu + 3, n - 1, n + 7, -3, 5])]).to(device)
+    deg = (pg.forward_op.rowptr[1:] - pg.forward_op.rowptr[:-1]).long()
+    for op, lo, hi in ((item_op, nu, n), (user_op, 0, nu)):
+        inside = (rows >= lo) & (rows < hi)
+        listed = torch.unique(rows[inside])
+        out = torch.full_like(x, float("nan"))
+        apply_rows(op, rows, x, out, a=0.5, r=r, b=0.25, split=True)
+        short, long_ = listed[deg[listed] <= 32], listed[deg[listed] > 32]
+        assert torch.equal(out[short], full[short])
+        if long_.numel():
+            assert rel_fro(out[long_].cpu(), full[long_].cpu()) <= 1e-6
+        mask = torch.ones(n, dtype=torch.bool, device=device)
+        mask[listed] = False
+        assert torch.isnan(out[mask]).all()                                # nothing else is written
+        comp = torch.full((rows.numel(), dim), float("nan"), device=device)
+        apply_rows(op, rows, x, comp, a=0.5, r=r, b=0.25, split=True, compact=True)
+        assert torch.equal(comp[inside], out[rows[inside]]) and torch.isnan(comp[~inside]).all()
+        again = torch.full_like(x, float("nan"))
+        apply_rows(op, rows, x, again, a=0.5, r=r, b=0.25, split=True)
+        assert torch.equal(again[listed], out[listed])                     # deterministic
+    assert (deg[nu:] > 256).sum() > 30                                     # rows of several chunks were among them
+    # a partial table with almost no room: the planning launch lengthens the chunks instead of overrunning it
+    monkeypatch.setattr(G, "ROWS_SPLIT_ROOM", 8)
+    G._rows_scratch.clear()
+    big = rows.repeat(9)[:4100].contiguous()
+    tight = torch.full_like(x, float("nan"))
+    apply_rows(item_op, big, x, tight, a=0.5, r=r, b=0.25, split=True)
+    listed = torch.unique(big[(big >= nu) & (big < n)])
+    assert rel_fro(tight[listed].cpu(), full[listed].cpu()) <= 1e-6
+    G._rows_scratch.clear()
+
+
+def test_scored_item_rows_only_is_the_full_forward_on_the_scored_rows(device, monkeypatch):
+    """The scoring node computes the last item step for the batch's item rows only (SCORED_ITEM_ROWS_ONLY): scores and
+    gradient against the same node with the full last item step, equal and unequal alphas."""
+    from gnn_ecommerce_amd import propagate
+    g, ei, ew = small_graph(5, 4000, 120, 60000)
+    n, nu = g.num_nodes, g.n_users
+    pg = PropGraph(ei.to(device), ew.to(device), n)
+    gen = torch.Generator().manual_seed(4)
+    m = 40
+    labels = torch.stack((torch.randint(0, nu, (m,), generator=gen), torch.randint(nu, n, (m,), generator=gen))).to(device)
+    monkeypatch.setattr(propagate, "SEED_ROWS_FACTOR", 1)
+    for alphas in ((0.25, 0.25, 0.25, 0.25), (0.4, 0.3, 0.2, 0.1)):
+        got = {}
+        for flag in (True, False):
+            monkeypatch.setattr(propagate, "SCORED_ITEM_ROWS_ONLY", flag)
+            w = synth.xavier_table(n, 64, 1, device).requires_grad_(True)
+            scores = propagate.scores_from_table(w, pg, alphas, labels)
+            scores.square().sum().backward()
+            got[flag] = (scores.detach().cpu(), w.grad.cpu())
+        assert rel_fro(got[True][0], got[False][0]) <= 1e-6 and rel_fro(got[True][1], got[False][1]) <= 1e-6
+
+
 @pytest.mark.parametrize("dim,layers,force_sweep", [(64, 3, False), (90, 5, False), (64, 2, True), (16, 1, False)])
 def test_equal_alphas_let_the_last_item_step_write_the_result(device, dim, layers, force_sweep, monkeypatch):
     """With the reference's alpha = 1 / (K + 1) the last item step takes sum_{l<K} alpha x_l[items] as its epilogue row and
