@@ -778,6 +778,13 @@ def scores_from_table(w: Tensor, graph: PropGraph, alphas: Sequence[float], edge
                  and USE_BIPARTITE and len(alphas) - 1 <= _native.MAX_TERMS - 1
                  and 2 * edge_label_index.size(1) * SEED_ROWS_FACTOR <= w.size(0))   # a seed far smaller than the table
     if not sparse_ok:
+        few = (SCORED_ROWS_ONLY and graph.split is not None and USE_BIPARTITE and len(alphas) - 1 <= _native.MAX_TERMS - 1
+               and len(alphas) > 1 and 2 * edge_label_index.size(1) * SEED_ROWS_FACTOR <= w.size(0))
+        if few and not (torch.is_grad_enabled() and w.requires_grad):
+            # scoring a few pairs without gradients (an evaluation batch under no_grad): the last user step and the last
+            # item step for the rows the pairs name only, like the training forward
+            rows = edge_label_index.reshape(-1).clamp(0, w.size(0) - 1)
+            return pair_dot(_layer_sum(graph, w.detach().contiguous(), alphas, transpose=False, final_rows=rows), edge_label_index)
         return pair_dot(propagate_sum(w, graph, alphas), edge_label_index)
     scores, token = _ScoresFromTable.apply(w, graph, alphas, edge_label_index[0], edge_label_index[1], hook)
     if hook is not None:

@@ -1026,6 +1026,13 @@ def test_scored_item_rows_only_is_the_full_forward_on_the_scored_rows(device, mo
             scores.square().sum().backward()
             got[flag] = (scores.detach().cpu(), w.grad.cpu())
         assert rel_fro(got[True][0], got[False][0]) <= 1e-6 and rel_fro(got[True][1], got[False][1]) <= 1e-6
+        # ... and without gradients (an evaluation batch): the same listed-rows forward, against the full table
+        monkeypatch.setattr(propagate, "SCORED_ITEM_ROWS_ONLY", True)
+        w = synth.xavier_table(n, 64, 1, device)
+        with torch.no_grad():
+            few = propagate.scores_from_table(w, pg, alphas, labels)
+            want = propagate.pair_dot(propagate.propagate_sum(w, pg, alphas), labels)
+        assert rel_fro(few.cpu(), want.cpu()) <= 1e-6
 
 
 @pytest.mark.parametrize("dim,layers,force_sweep", [(64, 3, False), (90, 5, False), (64, 2, True), (16, 1, False)])
