@@ -113,6 +113,8 @@ SIGNATURES = {
                                 c_int32, c_void_p]),
     "lgc_pair_dot_rows": (c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p]),
+    "lgc_reg_rows": (c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float,
+                             c_void_p, c_void_p, c_void_p, c_void_p]),
     "lgc_bpr_loss": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "lgc_pair_seed_vals": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "lgc_seed_prepare": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

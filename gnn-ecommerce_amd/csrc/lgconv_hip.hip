@@ -1832,6 +1832,69 @@ __global__ __launch_bounds__(kSeedBlock) void k_bpr_loss(const float *__restrict
     if (threadIdx.x == 0) loss[0] = -part[0] * inv_size;
 }
 
+// The regulariser of src/utils_v2.py:193-211 on three id lists of one table (lgc_reg_rows): what
+//   (1/2) * (w[u].norm().pow(2) + w[p].norm().pow(2) + w[n].norm().pow(2)) / size * decay
+// costs as 13 torch launches (three gathers into [B, D] copies, three norms, pows, adds, scalings) plus nine more that
+// normalise the ids for the gradient's row list -- in ONE workgroup: a thread per row (columns in order), per-list sums of
+// squares added up in a fixed order (the same bits on every run),
+// value = scale * ((sqrt S_u)^2 + (sqrt S_p)^2 + (sqrt S_n)^2) like the expression above.  rows_out (int64 [m0 + m1 + m2],
+// optional): the ids as row numbers, negative ids wrapped (torch's indexing), an id outside [-n_rows, n_rows) as -1 = "no
+// row" -- such an id contributes nothing and sets LGC_ST_INDEX_OOB (upstream's gather raises).
+__global__ __launch_bounds__(kSeedBlock) void k_reg_rows(const float *__restrict__ w, int64_t stride, int32_t dim, int64_t n_rows,
+                                                        const int64_t *__restrict__ ids0, int64_t m0,
+                                                        const int64_t *__restrict__ ids1, int64_t m1,
+                                                        const int64_t *__restrict__ ids2, int64_t m2, float scale,
+                                                        float *__restrict__ value, int64_t *__restrict__ rows_out,
+                                                        int32_t *__restrict__ status) {
+    constexpr int kWaves = kSeedBlock / kWave;
+    __shared__ float part[3][kWaves];
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    const int64_t total = m0 + m1 + m2;
+    float acc[3] = {0.0f, 0.0f, 0.0f};
+    // a THREAD per row (a wavefront per row made one workgroup walk 3 B rows through two dependent loads each: 200 us): the
+    // dim / 4 loads of a row are independent, a thread has all of them in flight
+    for (int64_t t = threadIdx.x; t < total; t += kSeedBlock) {
+        const int which = t < m0 ? 0 : (t < m0 + m1 ? 1 : 2);
+        int64_t id = which == 0 ? ids0[t] : (which == 1 ? ids1[t - m0] : ids2[t - m0 - m1]);
+        if (id < 0) id += n_rows;
+        const bool ok = id >= 0 && id < n_rows;
+        if (rows_out != nullptr) rows_out[t] = ok ? id : -1;
+        if (!ok) {
+            atomicOr(status, LGC_ST_INDEX_OOB);
+            continue;
+        }
+        const float *row = w + id * stride;
+        float sq = 0.0f;
+        int c = 0;
+        for (; c + 4 <= dim; c += 4) {
+            const f4 v = *reinterpret_cast<const f4u *>(row + c);
+            sq += v.x * v.x;
+            sq += v.y * v.y;
+            sq += v.z * v.z;
+            sq += v.w * v.w;
+        }
+        for (; c < dim; ++c) sq += row[c] * row[c];
+        acc[which] += sq;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float v = acc[j];
+        for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) part[j][wv] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float out = 0.0f;
+        for (int j = 0; j < 3; ++j) {
+            float sum = 0.0f;
+            for (int i = 0; i < kWaves; ++i) sum += part[j][i];
+            const float nrm = sqrtf(sum);
+            out += nrm * nrm;
+        }
+        value[0] = out * scale;
+    }
+}
+
 struct LincombArgs {
     const float *src[LGC_MAX_TERMS];
     int64_t stride[LGC_MAX_TERMS];
@@ -3759,6 +3822,16 @@ int lgc_bpr_loss(const float *scores, const uint8_t *mask, int64_t n_triples, in
     if (n_triples > 0 && (!scores || !grad)) return LGC_E_INVAL;
     hipLaunchKernelGGL(k_bpr_loss, dim3(1), dim3(kSeedBlock), 0, as_stream(stream_), scores, mask, n_triples,
                        1.0f / (float)size, loss, grad);
+    return (int)hipGetLastError();
+}
+
+int lgc_reg_rows(const float *w, int64_t stride, int32_t dim, int64_t n_rows, const int64_t *ids0, int64_t m0, const int64_t *ids1,
+                 int64_t m1, const int64_t *ids2, int64_t m2, float scale, float *value, int64_t *rows_out, int32_t *status,
+                 void *stream_) {
+    if (!w || !value || !status || dim < 1 || stride < dim || n_rows < 0 || m0 < 0 || m1 < 0 || m2 < 0) return LGC_E_INVAL;
+    if ((m0 > 0 && !ids0) || (m1 > 0 && !ids1) || (m2 > 0 && !ids2)) return LGC_E_INVAL;
+    hipLaunchKernelGGL(k_reg_rows, dim3(1), dim3(kSeedBlock), 0, as_stream(stream_), w, stride, dim, n_rows, ids0, m0, ids1, m1, ids2,
+                       m2, scale, value, rows_out, status);
     return (int)hipGetLastError();
 }
 

@@ -21,8 +21,8 @@ from torch.nn.modules.loss import _Loss
 from . import _native
 from .graph import get_graph
 from .lgconv import LGConv
-from .propagate import (TOPK_MAX, RegHook, SeenLists, mask_topk, pair_dot, propagate_sum, regularization_through,
-                        routable_index, scores_from_table)
+from .propagate import (TOPK_MAX, RegHook, SeenLists, bpr_loss_fused, mask_topk, pair_dot, propagate_sum,
+                        regularization_through, routable_index, scores_from_table)
 
 __all__ = ["LightGCN", "BPRLoss", "LGConv", "regularization_loss"]
 
@@ -235,6 +235,10 @@ class BPRLoss(_Loss):
 
     def forward(self, positives: Tensor, negatives: Tensor, parameters: Tensor = None) -> Tensor:
         n_pairs = positives.size(0)
+        if self.lambda_reg == 0 and positives.dim() == 1:
+            fused = bpr_loss_fused(positives, negatives)      # the same value and gradient in one launch each way
+            if fused is not None:
+                return fused
         loss = -F.logsigmoid(positives - negatives).mean()
         if self.lambda_reg != 0:
             loss = loss + self.lambda_reg * parameters.norm(p=2).pow(2)

@@ -500,6 +500,21 @@ class DeviceOps:
         _native.check(code, "lgc_bpr_loss")
         return out[0], out[1:]
 
+    def reg_rows(self, w: Tensor, lists: Sequence[Tensor], scale: float):
+        """(value 0-dim, rows int64 [sum of lengths]): lgc_reg_rows -- scale * sum over the three id lists of |w[ids]|_F^2 and
+        the ids as row numbers (negative ids wrapped, out-of-range ones -1 and reported through the index status)."""
+        lib = _native.load()
+        dev = w.device
+        a, b, c = lists
+        value = torch.empty(1, dtype=torch.float32, device=dev)
+        rows = torch.empty(a.numel() + b.numel() + c.numel(), dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            code = lib.lgc_reg_rows(_native.ptr(w), w.stride(0), w.size(1), w.size(0), _native.ptr(a), a.numel(), _native.ptr(b),
+                                    b.numel(), _native.ptr(c), c.numel(), float(scale), _native.ptr(value), _native.ptr(rows),
+                                    _native.ptr(_status(dev)), _native.stream_of(dev))
+        _native.check(code, "lgc_reg_rows")
+        return value[0], rows
+
     def seed_mark(self, op: Operator, rows_sorted: Tensor, mark: Tensor, value: int) -> None:
         _seed_mark(op, rows_sorted, mark, value)
 
@@ -694,8 +709,14 @@ class _ScoresFromTable(torch.autograd.Function):
         n_nodes = w.size(0)
         # only the rows the pairs name are read below (clamped like the gathers that follow, so that every row that is
         # gathered has been computed): the last user step is restricted to them
-        rows = torch.cat([idx0, idx1])
-        emb = _layer_sum(graph, w.detach(), alphas, transpose=False, final_rows=rows.clamp(0, n_nodes - 1))
+        # (ids outside the table are skipped by the listed-rows launches and scored NaN below: no clamp; the two rows of one
+        # contiguous [2, M] label tensor are one vector already: no cat)
+        m = idx0.numel()
+        if (idx1.data_ptr() == idx0.data_ptr() + 8 * m and idx0.untyped_storage().data_ptr() == idx1.untyped_storage().data_ptr()):
+            rows = idx0.as_strided((2 * m,), (1,))
+        else:
+            rows = torch.cat([idx0, idx1])
+        emb = _layer_sum(graph, w.detach(), alphas, transpose=False, final_rows=rows)
         # one launch: the scores, the two gathered rows of every pair and a validity byte (an invalid pair scores NaN,
         # keeps zero rows and carries no gradient)
         scores, e0, e1, ok = DEVICE_OPS.pair_scores_rows(emb, idx0, idx1)
@@ -741,14 +762,61 @@ class _RegThroughHook(torch.autograd.Function):
 
 
 def regularization_through(hook: RegHook, size: int, users: Tensor, pos: Tensor, neg: Tensor, decay: float) -> Tensor:
-    """The regulariser of src/utils_v2.py:193-211 on ``hook.weight``, its gradient routed into the scoring node."""
+    """The regulariser of src/utils_v2.py:193-211 on ``hook.weight``, its gradient routed into the scoring node.  Value and
+    row list in ONE launch (lgc_reg_rows) when the table qualifies (fp32, unit inner stride): upstream's expression is 13
+    small launches plus nine that normalise the ids -- 0.13 ms of a 3.4 ms step."""
     w = hook.weight.detach()
-    value = (1 / 2) * (w[users].norm().pow(2) + w[pos].norm().pow(2) + w[neg].norm().pow(2)) / size * decay
-    # upstream's gathers take CPU or int32 index tensors and negative (wrapping) ids on a CUDA table; the scoring node's
-    # backward hands these rows to lgc_segment_sum as raw int64 device pointers, so they are normalised here
-    rows = torch.cat([regularizer_rows(t, w) for t in (users, pos, neg)])
+    # upstream's gathers take CPU or int32 index tensors and negative (wrapping) ids on a CUDA table; the kernels take raw
+    # int64 device pointers, so the lists are normalised here (no launch when they already are int64 on the device)
+    lists = [t.reshape(-1).to(device=w.device, dtype=torch.int64).contiguous() for t in (users, pos, neg)]
+    if FUSED_GLUE and w.dtype == torch.float32 and w.dim() == 2 and w.stride(1) == 1:
+        value, rows = DEVICE_OPS.reg_rows(w, lists, 0.5 * float(decay) / float(size))
+    else:
+        value = (1 / 2) * (w[users].norm().pow(2) + w[pos].norm().pow(2) + w[neg].norm().pow(2)) / size * decay
+        rows = torch.cat([torch.where(r < 0, r + w.size(0), r) for r in lists])
     hook.terms.append((rows, float(decay) / float(size)))
     return _RegThroughHook.apply(hook.token, value)
+
+
+# the step's glue around the scoring node as single launches (lgc_reg_rows, lgc_bpr_loss); "0": upstream's torch expressions
+FUSED_GLUE = os.environ.get("LGCN_FUSED_GLUE", "1") == "1"
+
+
+class _BprLoss(torch.autograd.Function):
+    """-mean(log sigmoid(pos - neg)) / n_pairs (src/lightgcn.py:262-286 with lambda_reg = 0) and its gradient in one launch
+    (lgc_bpr_loss) instead of five forward and six backward launches of elementwise torch kernels."""
+
+    @staticmethod
+    def forward(ctx, positives: Tensor, negatives: Tensor) -> Tensor:
+        n = positives.numel()
+        pos, neg = positives.reshape(-1), negatives.reshape(-1)
+        if (pos.is_contiguous() and neg.is_contiguous() and neg.data_ptr() == pos.data_ptr() + 4 * n
+                and pos.untyped_storage().data_ptr() == neg.untyped_storage().data_ptr()):
+            scores = pos.as_strided((2 * n,), (1,))            # out[:B], out[B:] of one score vector: no copy
+        else:
+            scores = torch.cat([pos, neg])
+        loss, grad = DEVICE_OPS.bpr_loss(scores, None, n * n)   # -sum log sigmoid / n^2
+        ctx.save_for_backward(grad)
+        ctx.shapes = (positives.shape, negatives.shape)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out: Tensor):
+        (grad,) = ctx.saved_tensors
+        g = grad * grad_out
+        n = g.numel() // 2
+        return g[:n].reshape(ctx.shapes[0]), g[n:].reshape(ctx.shapes[1])
+
+
+def bpr_loss_fused(positives: Tensor, negatives: Tensor) -> Optional[Tensor]:
+    """``BPRLoss(0)(positives, negatives)`` through lgc_bpr_loss, or None when the inputs do not qualify (then the caller
+    evaluates upstream's expression on torch ops)."""
+    if (FUSED_GLUE and positives.is_cuda and negatives.is_cuda and positives.dtype == torch.float32
+            and negatives.dtype == torch.float32 and positives.shape == negatives.shape and positives.numel() > 0
+            and positives.device == negatives.device and positives.numel() <= 1 << 20):
+        return _BprLoss.apply(positives, negatives)
+    return None
 
 
 def routable_index(t) -> bool:

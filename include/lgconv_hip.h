@@ -415,6 +415,17 @@ int lgc_pair_dot_rows(const float *emb, int64_t stride, int32_t dim, int64_t n_n
                       int64_t n_pairs, float *scores, float *rows0, float *rows1, uint8_t *ok, int32_t *status, void *stream);
 int lgc_bpr_loss(const float *scores, const uint8_t *mask, int64_t n_triples, int64_t size, float *loss, float *grad,
                  void *stream);
+/* The regulariser of src/utils_v2.py:193-211 (called at src/train_lightgcn.py:142) in one launch (ABI 12):
+ *   value[0] = scale * (|w[ids0]|_F^2 + |w[ids1]|_F^2 + |w[ids2]|_F^2)      scale = decay / (2 * batch_size)
+ * each norm as (sqrt(sum of squares))^2 like `init_embed[batch].norm().pow(2)`; ids int64 device lists of m0 / m1 / m2
+ * entries (a list may be empty), negative ids wrap like torch's indexing.  rows_out (int64 [m0 + m1 + m2] or NULL): the ids
+ * as row numbers in list order -- the rows the regulariser's gradient decay / size * w[row] goes to (lgc_segment_sum); an id
+ * outside [-n_rows, n_rows) contributes nothing, comes out as -1 ("no row") and sets LGC_ST_INDEX_OOB in `status` (upstream's
+ * gather raises IndexError).  One workgroup, fixed reduction order: the same bits on every run. */
+int lgc_reg_rows(const float *w, int64_t stride, int32_t dim, int64_t n_rows, const int64_t *ids0, int64_t m0, const int64_t *ids1,
+                 int64_t m1, const int64_t *ids2, int64_t m2, float scale, float *value, int64_t *rows_out, int32_t *status,
+                 void *stream);
+
 int lgc_pair_seed_vals(const float *grad_scores, const uint8_t *mask, const float *grad_scale, const float *rows0,
                        const float *rows1, int64_t n_pairs, int32_t dim, float *vals, void *stream);
 int lgc_seed_prepare(const int64_t *rows, int64_t m, int64_t split, int64_t n_nodes, int64_t *rows_sorted, int32_t *perm,

@@ -363,6 +363,10 @@ def test_argument_errors_of_the_round3_entry_points():
     assert split(yr=3) == -1 and split(compact=1, yr=2) == -1                      # y must hold every row that may be written
     assert split(work=None) == -1 and split(part=None) == -1 and split(pr=3) == -4 and split(pr=2) == -4
     assert split(n=0) == 0
+    reg = lambda **kw: lib.lgc_reg_rows(kw.get("w", one), kw.get("stride", 64), kw.get("dim", 64), 100, kw.get("a", one), kw.get("m0", 4),
+                                        one, 4, one, kw.get("m2", 4), 0.5, kw.get("value", two), None, kw.get("status", two), None)
+    assert reg(w=None) == -1 and reg(value=None) == -1 and reg(status=None) == -1 and reg(stride=32) == -1 and reg(dim=0) == -1
+    assert reg(m0=-1) == -1 and reg(a=None) == -1 and reg(m2=-1) == -1
     cb = _native.EXCHANGE_FN(lambda *a: 0)
     op = _native.OperatorC()
     assert lib.lgc_hop_exchange(ctypes.byref(op), ctypes.byref(op), 100, one, 64, two, 64, None, 0, 1.0, 0.0, 64, 90, 20, 1, cb,
