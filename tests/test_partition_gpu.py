@@ -380,3 +380,24 @@ def test_eight_ranks_at_full_size_on_one_gpu(device):
         assert r["own"] <= 1e-5 and r["items"] <= 1e-5 and r["worst"] <= 1e-5, (rank, r)
         assert r["bpr"] <= 1e-5 and r["reg"] <= 1e-5 and r["g_own"] <= 1e-5 and r["g_items"] <= 1e-5, (rank, r)
         assert r["w_own"] <= 1e-4 and r["w_items"] <= 1e-4, (rank, r)
+
+
+def test_the_multi_gpu_training_harness_runs_two_ranks_on_one_gpu(device):
+    """tools/train_dist.py (configs[4] on N GPUs: one process per GPU, PartitionedTrainer) rehearsed with two ranks on this
+    one GPU over gloo, eager and recorded: one JSON line from rank 0, a finite decreasing-from-ln2 loss, the same loss from
+    the recorded step."""
+    import json
+    import subprocess
+    lines = []
+    for extra in ([], ["--graphs"]):
+        proc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_dist.py"), "--gpus", "2", "--backend", "gloo",
+                               "--config", "small", "--steps", "6", "--warmup", "4", "--batch", "256"] + extra,
+                              capture_output=True, text=True, timeout=600)
+        assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
+        found = [json.loads(ln) for ln in proc.stdout.splitlines() if ln.startswith("{")]
+        assert len(found) == 1
+        lines.append(found[0])
+    for line in lines:
+        assert line["n_gpus"] == 2 and line["unit"] == "steps/s" and line["value"] > 0
+        assert 0.0 < line["loss"]["bpr"] < 0.6932 and line["loss"]["reg"] > 0
+    assert abs(lines[0]["loss"]["total"] - lines[1]["loss"]["total"]) <= 1e-6 * lines[0]["loss"]["total"]
