@@ -35,6 +35,9 @@ from .graph import CHUNK_LEN, SHORT_MAX, Operator, PropGraph, build_row_plan
 from .propagate import DeviceOps
 
 
+import warnings
+warnings.filterwarnings("ignore", message=r"index_reduce\(\) is in beta")    # used once per step (propagate_sum, listed item rows)
+
 ITEM_SHORT_MAX = int(os.environ.get("LGCN_ITEM_SHORT_MAX", "32"))   # 8 / 16 / 32: 114 / 113 / 112 us per hop at world 8, 202 -> 190 at world 4
 
 
@@ -288,7 +291,10 @@ class PartitionedPropagator:
                     else:
                         rest = cur
                         self._lincomb(rest[nu:], [(alphas[l], tables[l][nu:]) for l in range(0, k)])
-                    out[listed] = torch.add(rest[listed], part, alpha=alphas[k])
+                    # a repeated id holds the same sum at each of its list positions up to the association the all-reduce
+                    # used for that position (a ring reduces different chunks of the buffer in different rank orders):
+                    # taking the elementwise maximum over the repeats makes the row independent of the order of the writes
+                    out.index_reduce_(0, listed, torch.add(rest[listed], part, alpha=alphas[k]), "amax", include_self=False)
                 elif uniform:
                     # equal alphas (the reference's 1 / (K + 1)): sum_{l<=K} a x_l = mix + a x_K, the same chain of adds
                     # (((a x_0 + a x_1) + a x_2) + a x_3), two 14 MB reads instead of K + 1
