@@ -467,6 +467,7 @@ class Operator:
     _tiles: Optional[List[TileClass]] = None
     _partials: Dict[int, Tensor] = field(default_factory=dict)
     _c_structs: Dict[tuple, list] = field(default_factory=dict)
+    _row_stats: Optional[tuple] = None
 
     @classmethod
     def build(cls, n_rows: int, rowptr: Tensor, entries: Tensor, row_begin: int, row_end: int,
@@ -535,6 +536,25 @@ class Operator:
     @property
     def nnz(self) -> int:
         return self.entries.size(0)
+
+    def listed_rows_pay(self, n_ids: int) -> bool:
+        """Whether running this half for a LIST of rows (``apply_rows(split=True)``: the last item step of a scoring
+        forward) is expected to beat the full step.  The list's work is the sum of its rows' lengths, repeats included,
+        gathered at the all-miss price (about twice what the full step pays per entry), and a training batch's positives
+        are drawn in proportion to popularity (src/utils_v2.py:168-181: a random purchase of a random user): with half of
+        ~n_ids / 2 listed rows of this half drawn that way and half uniformly, the expected work is
+        n_ids / 4 * (sum d^2 / sum d + sum d / rows).  Listed rows are used while that stays below LISTED_ROWS_MAX_SHARE of
+        the half's entries -- on the cosmetics-shaped graph 3.3 M of 10.2 M entries for 2 x 1024 pairs (uniform triples:
+        0.4 M); a graph whose hubs are heavier keeps the full step.  One host sync, once per operator."""
+        if self._row_stats is None:
+            p = self.plan
+            deg = (self.rowptr[p.row_begin + 1:p.row_end + 1] - self.rowptr[p.row_begin:p.row_end]).double()
+            s1, s2 = torch.stack((deg.sum(), (deg * deg).sum())).tolist()
+            self._row_stats = (s1, s2, max(p.row_end - p.row_begin, 1))
+        s1, s2, rows = self._row_stats
+        if s1 <= 0:
+            return True
+        return n_ids / 4.0 * (s2 / s1 + s1 / rows) <= LISTED_ROWS_MAX_SHARE * s1
 
     def partials(self, dim: int) -> Optional[Tensor]:
         n_slots = self.plan.n_slots
@@ -613,6 +633,7 @@ class Operator:
 
 
 _rows_scratch: Dict[tuple, Tuple[Tensor, Tensor]] = {}
+LISTED_ROWS_MAX_SHARE = float(os.environ.get("LGCN_LISTED_ROWS_MAX_SHARE", "0.4"))   # Operator.listed_rows_pay
 ROWS_SPLIT_ROOM = 16384      # partial rows beyond one per list position: 128-entry chunks up to 2 M listed entries
 
 

@@ -254,6 +254,8 @@ class PartitionedPropagator:
         out = torch.zeros_like(x0) if zero_foreign_rows else torch.empty_like(x0)
         pending = [None] * (k + 1)                                   # all-reduce of x_l[items]
         listed_items = final_item_rows is not None and final_rows is not None and propagate.SCORED_ITEM_ROWS_ONLY
+        if listed_items and hasattr(item_op, "listed_rows_pay"):            # (arithmetic test doubles have no such method)
+            listed_items = item_op.listed_rows_pay(2 * final_item_rows.numel())
         uniform = all(a == alphas[0] for a in alphas)
         marks = []
         for layer in range(1, k + 1):

@@ -134,7 +134,7 @@ def bipartite_sum(user_op: Operator, item_op: Operator, split: int, x0: Tensor, 
             else:
                 out = torch.empty_like(x0)
                 rows_only = final_rows is not None
-                if rows_only and SCORED_ITEM_ROWS_ONLY:
+                if rows_only and SCORED_ITEM_ROWS_ONLY and item_op.listed_rows_pay(final_rows.numel()):
                     # the scores read the item block at the batch's item rows only: the last item step -- a full sweep over
                     # the 420 MB user table otherwise -- is computed for the listed rows (lgc_spmm_rows_split: the rows cut
                     # into chunks on the device), on top of rest = sum_{l<K} alpha_l x_l[items]

@@ -1009,7 +1009,8 @@ def test_listed_long_rows_are_cut_into_chunks_on_the_device(device, dim, monkeyp
 def test_scored_item_rows_only_is_the_full_forward_on_the_scored_rows(device, monkeypatch):
     """The scoring node computes the last item step for the batch's item rows only (SCORED_ITEM_ROWS_ONLY): scores and
     gradient against the same node with the full last item step, equal and unequal alphas."""
-    from gnn_ecommerce_amd import propagate
+    from gnn_ecommerce_amd import graph as G, propagate
+    monkeypatch.setattr(G, "LISTED_ROWS_MAX_SHARE", 1e9)        # a graph this small would keep the full step (see below)
     g, ei, ew = small_graph(5, 4000, 120, 60000)
     n, nu = g.num_nodes, g.n_users
     pg = PropGraph(ei.to(device), ew.to(device), n)
@@ -1033,6 +1034,14 @@ def test_scored_item_rows_only_is_the_full_forward_on_the_scored_rows(device, mo
             few = propagate.scores_from_table(w, pg, alphas, labels)
             want = propagate.pair_dot(propagate.propagate_sum(w, pg, alphas), labels)
         assert rel_fro(few.cpu(), want.cpu()) <= 1e-6
+    # the guard: listed rows only while their expected work (half of them drawn by popularity) stays well below the step's
+    monkeypatch.setattr(G, "LISTED_ROWS_MAX_SHARE", 0.4)
+    _, item_op = pg.halves()
+    deg = (item_op.rowptr[nu + 1:n + 1] - item_op.rowptr[nu:n]).double()
+    s1, s2 = deg.sum().item(), (deg * deg).sum().item()
+    for n_ids in (8, 80, 800, 8000):
+        assert item_op.listed_rows_pay(n_ids) == (n_ids / 4 * (s2 / s1 + s1 / (n - nu)) <= 0.4 * s1)
+    assert item_op.listed_rows_pay(8) and not item_op.listed_rows_pay(8000)
 
 
 @pytest.mark.parametrize("dim", [64, 90])

@@ -25,6 +25,8 @@ def _init(rank, world, port, backend):
     """gloo: every rank on cuda:0.  nccl (= RCCL): one rank per GPU, as the driver launches bench.py."""
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # graphs this small would keep the full last item step (Operator.listed_rows_pay): the listed-rows exchange is what is tested
+    os.environ.setdefault("LGCN_LISTED_ROWS_MAX_SHARE", "1e9")
     dev = torch.device(f"cuda:{rank}" if backend == "nccl" else "cuda:0")
     torch.cuda.set_device(dev)
     if backend == "nccl":
