@@ -14,6 +14,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a ROCm device (run on the MI355X box with -m gpu)")
+    config.addinivalue_line("filterwarnings", r"ignore:index_reduce\(\) is in beta")     # partition.propagate_sum, once per step
 
 
 def load_golden(name):

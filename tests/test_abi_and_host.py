@@ -668,3 +668,17 @@ def test_plain_c_host_drives_the_abi(tmp_path):
     assert build.returncode == 0, build.stderr
     run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0 and run.stdout.startswith("ok "), (run.returncode, run.stdout, run.stderr)
+
+
+def test_listed_rows_guard_follows_the_degree_moments():
+    """Operator.listed_rows_pay (host logic, no launch): listed rows for the last item step of a scoring forward only while
+    a popularity-drawn batch's expected work stays below LISTED_ROWS_MAX_SHARE of the half's entries."""
+    from gnn_ecommerce_amd.graph import Operator
+    flat = torch.arange(0, 1001, dtype=torch.int32) * 100                     # 1000 rows of 100 entries
+    op = Operator.build(1000, flat, torch.zeros((100_000, 2), dtype=torch.int32), 0, 1000)
+    assert op.listed_rows_pay(800) and not op.listed_rows_pay(808)            # n / 4 * (100 + 100) <= 0.4 * 100,000
+    hub = torch.cat([torch.arange(0, 999, dtype=torch.int32) * 50, torch.tensor([49_950, 100_000], dtype=torch.int32)])
+    heavy = Operator.build(1000, hub, torch.zeros((100_000, 2), dtype=torch.int32), 0, 1000)   # one row holds half of all entries
+    assert heavy.listed_rows_pay(4) and not heavy.listed_rows_pay(8)         # n / 4 * (25,075 + 100) <= 40,000
+    empty = Operator.build(4, torch.zeros(5, dtype=torch.int32), torch.zeros((0, 2), dtype=torch.int32), 0, 4)
+    assert empty.listed_rows_pay(10 ** 6)
