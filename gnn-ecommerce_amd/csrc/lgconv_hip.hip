@@ -557,7 +557,10 @@ __global__ __launch_bounds__(kBlock) void k_spmm_rows(SpmmArgs p, const int64_t 
 // a partial row; k_rows_combine adds the partial rows of a position in chunk order and applies the epilogue.  A repeated
 // id is computed once per occurrence and written with the same bits.
 constexpr int kRowsPlanBlock = 1024;
-constexpr int kRowsChunk = 128;   // 256: +0.7 % on the training step (twice the chunks run side by side)
+#ifndef LGC_ROWS_CHUNK            // (-DLGC_ROWS_CHUNK=128 builds the A/B variant of profiles/r04g)
+#define LGC_ROWS_CHUNK 256
+#endif
+constexpr int kRowsChunk = LGC_ROWS_CHUNK;   // 128: the same step time (five interleaved pairs)
 
 __global__ __launch_bounds__(kRowsPlanBlock) void k_rows_plan(const int32_t *__restrict__ rowptr, const int64_t *__restrict__ row_ids,
                                                               int64_t n_ids, int32_t row_begin, int32_t row_end, int64_t cap,

@@ -634,7 +634,7 @@ class Operator:
 
 _rows_scratch: Dict[tuple, Tuple[Tensor, Tensor]] = {}
 LISTED_ROWS_MAX_SHARE = float(os.environ.get("LGCN_LISTED_ROWS_MAX_SHARE", "0.4"))   # Operator.listed_rows_pay
-ROWS_SPLIT_ROOM = 16384      # partial rows beyond one per list position: 128-entry chunks up to 2 M listed entries
+ROWS_SPLIT_ROOM = 16384      # partial rows beyond one per list position: 256-entry chunks up to 4 M listed entries
 
 
 def _rows_split_scratch(device: torch.device, n_ids: int, dim: int) -> Tuple[Tensor, Tensor]:

@@ -207,7 +207,7 @@ int lgc_spmm_rows(const int32_t *rowptr, const lgc_entry *entries, int32_t row_b
  * item step's [n_items, D] block is ever read -- but an item row holds 186 entries on average and a hub beyond 10^5, which
  * one wavefront per row cannot balance.  The listed rows are cut into chunks ON THE DEVICE (no host round trip, fixed launch
  * shapes: the step can be recorded as a HIP graph): a one-workgroup planning launch (entries of the listed rows -> chunk
- * length: 128 entries, or longer when `partial_rows` would not hold that many chunks -> first chunk number of every list
+ * length: 256 entries, or longer when `partial_rows` would not hold that many chunks -> first chunk number of every list
  * position), a fixed grid of wavefronts striding over the chunk numbers (rows of up to 32 entries finish in entry order
  * with the bits of lgc_spmm_tiles; longer single-chunk rows finish directly; the others leave partial rows), and one
  * wavefront per cut position adding its partial rows in chunk order: deterministic, no float atomics.
@@ -217,7 +217,7 @@ int lgc_spmm_rows(const int32_t *rowptr, const lgc_entry *entries, int32_t row_b
  *                 partition all-reduces instead of the whole item block
  *   work          int32 [n_ids + 2] device scratch
  *   partials      fp32 [partial_rows, dim] device scratch, partial_rows > n_ids (LGC_E_RANGE otherwise); n_ids + 16384
- *                 keeps 128-entry chunks up to 2 M listed entries
+ *                 keeps 256-entry chunks up to 4 M listed entries
  * r (optional epilogue rows) is indexed by row id in both modes.  Three launches on `stream`. */
 int lgc_spmm_rows_split(const int32_t *rowptr, const lgc_entry *entries, int32_t row_begin, int32_t row_end,
                         const int64_t *row_ids, int64_t n_ids, int64_t table_rows, const float *x, int64_t x_stride, float *y,
