@@ -31,3 +31,22 @@ for r in ranks:
     print(f"world {world} rank {r}: users [{pp.u0},{pp.u1}) local nnz {pp.local_nnz}  compute {statistics.median(ts):.1f} us/hop"
           f"  host enqueue {statistics.median(host):.1f} us/hop")
     del pp
+    if os.environ.get("RANK_COMPUTE_GRAPH") == "1":
+        # the same forward recorded as ONE HIP graph (no collective inside: they are stubbed) and replayed back to back, against
+        # the eager forward issued back to back: what recording the compute segments of a forward could buy (VERDICT r3 #1c)
+        pp = PartitionedPropagator(ei, ew, g.n_users, g.n_items, r, world)
+        for _ in range(3):
+            pp.propagate_sum(x0, alphas)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            pp.propagate_sum(x0, alphas)
+        res = {}
+        for name, fn in (("eager", lambda: pp.propagate_sum(x0, alphas)), ("recorded", graph.replay)) * 3:
+            torch.cuda.synchronize(); s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(10):
+                fn()
+            e.record(); torch.cuda.synchronize()
+            res.setdefault(name, []).append(s.elapsed_time(e) / 30 * 1e3)
+        print(f"world {world} rank {r}: ten forwards back to back, us/hop: " + "; ".join(f"{k} {' / '.join(f'{v:.1f}' for v in vs)}" for k, vs in res.items()))
+        del pp, graph
