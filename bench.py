@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--no-rank-local", action="store_true", help="skip the rank-local measurement (one rank of an 8-way "
                     "partition on this GPU, collectives stubbed)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = auto)")
+    ap.add_argument("--no-graph", action="store_true", help="N > 1: the eager forward instead of the forward recorded as one HIP "
+                    "graph with its collectives (partition.RecordedForward)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
                     "to rehearse the N > 1 path with several ranks on ONE GPU)")
     return ap.parse_args()
@@ -335,11 +337,21 @@ def main():
         make_step = lambda x0, alphas: (lambda: propagate.propagate_sum(x0, pg, alphas))
         parallelism = "single"
     else:
-        from gnn_ecommerce_amd.partition import PartitionedPropagator
+        from gnn_ecommerce_amd.partition import PartitionedPropagator, RecordedForward
         pp = PartitionedPropagator(ei, ew, graph.n_users, graph.n_items, rank, world)
         torch.cuda.synchronize()
         t_build, t_plan = time.perf_counter() - t0, None
-        make_step = lambda x0, alphas: (lambda: pp.propagate_sum(x0, alphas))
+        recorded_steps = []
+        # the forward of one fixed table recorded once -- before the timed region -- as ONE HIP graph, the per-hop all-reduces
+        # and their waits included as graph edges (each eager collective costs a rank two cross-stream hand-offs, +23 us on a
+        # 94 us hop: profiles/r04k); every rank falls back to the eager forward together if any rank cannot capture
+        if args.no_graph:
+            make_step = lambda x0, alphas: (lambda: pp.propagate_sum(x0, alphas))
+        else:
+            def make_step(x0, alphas):
+                rec = RecordedForward(pp, x0, alphas)
+                recorded_steps.append(rec)
+                return rec
         parallelism = (f"user-range x{world}, items replicated, all-reduce [n_items,D]/hop over {args.backend}"
                        + ("" if args.backend == "nccl" else " (rehearsal, not RCCL)"))
     keep_coo = (ei, ew)
@@ -371,6 +383,8 @@ def main():
             elapsed = tmax.item()
         hop_ms = [s.elapsed_time(e) for s, e in hop_events]
         hop_mean_s = sum(hop_ms) / max(len(hop_ms), 1) * 1e-3
+        if not hop_ms:          # a replayed graph carries no per-hop events: the timed region's wall time per hop
+            hop_ms, hop_mean_s = [0.0] * (steps * layers), elapsed / (steps * layers)
         bmin = synth.algorithmic_bytes_per_layer(n, nnz, dim)
         achieved = bmin / hop_mean_s if hop_mean_s > 0 else 0.0
         return {"elapsed": elapsed, "hop_mean_s": hop_mean_s, "launches": len(hop_ms), "bmin": bmin, "achieved": achieved}
@@ -436,7 +450,10 @@ def main():
             "config": {"workload": f"{workload_name(args, world)}: {graph.n_users} users x {graph.n_items} items, "
                                    f"{nnz} directed edges, {args.layers} LGConv layers, emb_dim {args.dim}, "
                                    "get_embedding (K hops + fused layer sum)",
-                       "parallelism": parallelism, "seed": SEED,
+                       "parallelism": parallelism + ("" if world == 1 else (
+                           ", forward recorded as one HIP graph (collectives included)" if recorded_steps and recorded_steps[0].recorded
+                           else ", eager forward" + (f" (capture declined: {recorded_steps[0].error})" if recorded_steps and recorded_steps[0].error else ""))),
+                       "seed": SEED,
                        "graph_build_s": round(t_build, 3),
                        "plan_build_s": None if t_plan is None else round(t_plan, 3),
                        "synth_gen_s": round(t_gen, 1)},

@@ -346,6 +346,90 @@ class PartitionedPropagator:
         return table
 
 
+class RecordedForward:
+    """``pp.propagate_sum(x0, alphas)`` for one fixed input table, recorded ONCE as a HIP graph -- collectives included --
+    and replayed: ``rec = RecordedForward(pp, x0, alphas); out = rec()``.
+
+    Why: a rank's hop at 8 ranks is ~95 us of kernels, and every collective torch issues eagerly costs two cross-stream
+    hand-offs (launch stream -> RCCL's stream -> launch stream: event record, barrier packet, event wait).  Measured on one
+    MI355X with the rank's collectives going to a real one-rank ``nccl`` group (identities: no byte moves): 93.6 us per hop
+    with the collectives stubbed out, 116.6 eager, 95.5-97.7 with the whole forward -- all-reduces and their waits as graph
+    edges -- replayed (profiles/r04k).  RCCL's collectives are capturable like NCCL's; the capture itself executes nothing.
+
+    The result tensor is owned by the graph: every call overwrites and returns the SAME tensor (valid rows: own users + all
+    items).  ``x0`` is read in place at every replay (update it in place between calls).  Only attempted over ``nccl`` (gloo
+    moves CUDA tensors through the host from its own threads: not capturable).  If the capture fails on ANY rank, every rank
+    falls back to the eager forward -- the ranks agree on that through one MIN all-reduce, so they can never disagree about
+    who replays and who launches eagerly."""
+
+    def __init__(self, pp: "PartitionedPropagator", x0: Tensor, alphas: Sequence[float], warmup: int = 2):
+        self.pp, self.x0, self.alphas = pp, x0, tuple(float(a) for a in alphas)
+        self.graph, self.out, self.error = None, None, None
+        from . import propagate
+        for _ in range(max(warmup, 1)):                      # lazy plans, scratch tables, the communicator's first use
+            pp.propagate_sum(x0, self.alphas)
+        ok = 1
+        active = getattr(pp.comm, "active", pp.world > 1)
+        # only a backend whose collectives are stream operations can be captured: gloo moves CUDA tensors through the host
+        # from its own threads, and an attempt leaves the launch stream in a broken capture
+        capturable = not active or dist.get_backend(pp.group) == "nccl"
+        if x0.is_cuda and RECORD_FORWARD and capturable:
+            torch.cuda.synchronize(x0.device)
+            log, propagate.HOP_EVENT_LOG = propagate.HOP_EVENT_LOG, None     # timing events cannot be recorded into a graph
+            # The capture runs on a side stream and is ended in a ``finally``: whatever goes wrong inside, this thread is
+            # back on its own stream, which never was in capture mode, before anything else is launched.
+            graph, out = torch.cuda.CUDAGraph(), None
+            current = torch.cuda.current_stream(x0.device)
+            side = torch.cuda.Stream(x0.device)
+            side.wait_stream(current)
+            try:
+                with torch.cuda.stream(side):
+                    # thread_local: the backend's watchdog thread keeps polling its events while this thread captures
+                    graph.capture_begin(capture_error_mode="thread_local")
+                    try:
+                        out = pp.propagate_sum(x0, self.alphas)
+                    except Exception as exc:                  # noqa: BLE001 -- whatever the backend raises: eager it is
+                        self.error, ok = f"{type(exc).__name__}: {exc}", 0
+                    finally:
+                        try:
+                            with warnings.catch_warnings():   # (a capture that failed at its first launch is empty)
+                                warnings.filterwarnings("ignore", message="The CUDA Graph is empty")
+                                graph.capture_end()
+                        except Exception as exc:              # noqa: BLE001 -- an invalidated capture ends with an error
+                            self.error, ok = self.error or f"{type(exc).__name__}: {exc}", 0
+            except Exception as exc:                          # noqa: BLE001 -- capture_begin itself
+                self.error, ok = self.error or f"{type(exc).__name__}: {exc}", 0
+            finally:
+                propagate.HOP_EVENT_LOG = log
+            current.wait_stream(side)
+            if ok:
+                self.graph, self.out = graph, out
+        else:
+            ok = 0
+            if not capturable:
+                self.error = f"backend {dist.get_backend(pp.group)} cannot be captured"
+        if active:                                            # every rank replays, or none does
+            flag = torch.tensor([ok], dtype=torch.int32, device=x0.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=pp.group)
+            ok = int(flag.item())
+        if not ok:
+            self.graph, self.out = None, None
+
+    @property
+    def recorded(self) -> bool:
+        return self.graph is not None
+
+    def __call__(self) -> Tensor:
+        if self.graph is None:
+            return self.pp.propagate_sum(self.x0, self.alphas)
+        self.graph.replay()
+        return self.out
+
+
+# "0": RecordedForward never records (the eager forward, as before)
+RECORD_FORWARD = os.environ.get("LGCN_RECORD_FORWARD", "1") == "1"
+
+
 class _ExchangeHandle:
     """What PartitionedPropagator hands propagate.seeded_sum for one item block: the all-reduce in flight."""
 

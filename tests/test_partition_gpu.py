@@ -56,7 +56,19 @@ def _worker(rank, world, port, q, backend="gloo"):
             return ((a.double() - b.double()).norm() / b.double().norm()).item()
 
         lo, hi = pp.ranges[rank]
-        q.put((rank, {"own": rel(out[lo:hi], single[lo:hi]), "items": rel(out[g.n_users:], single[g.n_users:]),
+        # the forward recorded as one HIP graph with its collectives (capturable over RCCL; over gloo every rank falls back to
+        # the eager forward together): the same rows either way, and again after the input changed in place
+        from gnn_ecommerce_amd.partition import RecordedForward
+        rec = RecordedForward(pp, x0, alphas)
+        again = rec().clone()
+        x0.mul_(0.5)
+        half = rec().clone()
+        x0.mul_(2.0)
+        torch.cuda.synchronize()
+        same = (torch.equal(again[lo:hi], out[lo:hi]) and torch.equal(again[g.n_users:], out[g.n_users:])
+                and rel(half[lo:hi], 0.5 * out[lo:hi]) <= 1e-6 and rel(half[g.n_users:], 0.5 * out[g.n_users:]) <= 1e-6)
+        q.put((rank, {"recorded": rec.recorded, "recorded_same": bool(same),
+                      "own": rel(out[lo:hi], single[lo:hi]), "items": rel(out[g.n_users:], single[g.n_users:]),
                       "full": rel(full, single), "worst_row": ((full - single).norm(dim=1) / single.norm(dim=1)).max().item(),
                       "share": pp.local_nnz / g.nnz, "world": dist.get_world_size(), "backend": dist.get_backend()}))
     finally:
@@ -87,6 +99,7 @@ def test_two_ranks_one_gpu_match_single_gpu(device):
     for rank, r in results.items():
         assert r["own"] <= 1e-5 and r["items"] <= 1e-5 and r["full"] <= 1e-5 and r["worst_row"] <= 1e-5, (rank, r)
         assert 0.45 <= r["share"] <= 0.55
+        assert r["recorded_same"] and not r["recorded"], (rank, r)      # gloo cannot be captured: both ranks went eager, together
 
 
 def _uses_node(fn, name, depth=6):
@@ -403,3 +416,38 @@ def test_the_multi_gpu_training_harness_runs_two_ranks_on_one_gpu(device):
         assert line["n_gpus"] == 2 and line["unit"] == "steps/s" and line["value"] > 0
         assert 0.0 < line["loss"]["bpr"] < 0.6932 and line["loss"]["reg"] > 0
     assert abs(lines[0]["loss"]["total"] - lines[1]["loss"]["total"]) <= 1e-6 * lines[0]["loss"]["total"]
+
+
+def test_recorded_forward_replays_and_falls_back_cleanly(device):
+    """partition.RecordedForward on one rank (no process group): the forward as one replayed HIP graph gives the eager rows,
+    follows in-place changes of its input, and a capture that fails half way (a fault injected while capturing) leaves the
+    thread on a healthy stream with the eager forward."""
+    from gnn_ecommerce_amd import synth
+    from gnn_ecommerce_amd.partition import PartitionedPropagator, RecordedForward
+    g = synth.make_bipartite(20000, 1500, 150000, seed=3)
+    ei, ew = g.coo(device)
+    x0 = synth.xavier_table(g.num_nodes, 64, 2, device)
+    alphas = (0.4, 0.3, 0.2, 0.1)
+    pp = PartitionedPropagator(ei, ew, g.n_users, g.n_items, 0, 1)
+    want = pp.propagate_sum(x0, alphas).clone()
+    rec = RecordedForward(pp, x0, alphas)
+    assert rec.recorded and rec.error is None
+    assert torch.equal(rec(), want)
+    x0.mul_(2.0)
+    doubled = rec().clone()
+    x0.mul_(0.5)
+    assert ((doubled - 2.0 * want).norm() / want.norm()).item() <= 1e-6 and torch.equal(rec(), want)
+    real = pp.propagate_sum
+
+    def flaky(*a, **k):
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("injected while capturing")
+        return real(*a, **k)
+
+    pp.propagate_sum = flaky
+    broken = RecordedForward(pp, x0, alphas)
+    assert not broken.recorded and "injected" in broken.error
+    assert not torch.cuda.is_current_stream_capturing()
+    assert torch.equal(broken(), want)                                  # eager, on a healthy stream
+    pp.propagate_sum = real
+    assert RecordedForward(pp, x0, alphas).recorded                     # and the next capture works again

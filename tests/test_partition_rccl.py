@@ -27,6 +27,8 @@ def test_rccl_forward_matches_single_gpu(device):
     for rank, r in results.items():
         assert r["backend"] == "nccl" and r["world"] == world
         assert r["own"] <= 1e-5 and r["items"] <= 1e-5 and r["full"] <= 1e-5 and r["worst_row"] <= 1e-5, (rank, r)
+        assert r["recorded_same"], (rank, r)
+    assert len({r["recorded"] for r in results.values()}) == 1          # every rank replays, or none does
     assert abs(sum(r["share"] for r in results.values()) - 1.0) < 1e-6
 
 
@@ -45,6 +47,7 @@ def test_one_rank_goes_through_the_rccl_process_group(device, monkeypatch):
     fwd = run_ranks(_worker, 1, backend="nccl")[0]
     assert fwd["backend"] == "nccl" and fwd["world"] == 1
     assert fwd["own"] <= 1e-5 and fwd["items"] <= 1e-5 and fwd["full"] <= 1e-5 and fwd["worst_row"] <= 1e-5, fwd
+    assert fwd["recorded"] and fwd["recorded_same"], fwd    # the forward with its collectives as ONE replayed HIP graph
     r = run_ranks(_train_worker, 1, backend="nccl")[0]
     assert r["backend"] == "nccl" and r["world"] == 1
     assert r["bpr"] <= 1e-5 and r["reg"] <= 1e-5 and r["own"] <= 1e-5 and r["items"] <= 1e-5, r
