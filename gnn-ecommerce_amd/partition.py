@@ -372,7 +372,8 @@ class RecordedForward:
         active = getattr(pp.comm, "active", pp.world > 1)
         # only a backend whose collectives are stream operations can be captured: gloo moves CUDA tensors through the host
         # from its own threads, and an attempt leaves the launch stream in a broken capture
-        capturable = not active or dist.get_backend(pp.group) == "nccl"
+        backend = dist.get_backend(pp.group) if dist.is_initialized() else None      # None: collectives stubbed out (a harness)
+        capturable = not active or backend in (None, "nccl")
         if x0.is_cuda and RECORD_FORWARD and capturable:
             torch.cuda.synchronize(x0.device)
             log, propagate.HOP_EVENT_LOG = propagate.HOP_EVENT_LOG, None     # timing events cannot be recorded into a graph
@@ -407,8 +408,8 @@ class RecordedForward:
         else:
             ok = 0
             if not capturable:
-                self.error = f"backend {dist.get_backend(pp.group)} cannot be captured"
-        if active:                                            # every rank replays, or none does
+                self.error = f"backend {backend} cannot be captured"
+        if active and backend is not None:                    # every rank replays, or none does
             flag = torch.tensor([ok], dtype=torch.int32, device=x0.device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=pp.group)
             ok = int(flag.item())

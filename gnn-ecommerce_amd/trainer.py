@@ -51,7 +51,10 @@ class PartitionedTrainer:
     place; its rows other ranks own are never read or written.
 
     ``graphs=True``: the first call records the step (after ``warmup`` eager steps that build every lazy plan and
-    scratch buffer), later calls replay it.  Same launches, same order, same bits as the eager step."""
+    scratch buffer), later calls replay it.  Same launches, same order, same bits as the eager step.  ``graphs="full"``:
+    the whole step as ONE graph with its collectives inside (RCCL's collectives are capturable; an eager collective costs a
+    rank two cross-stream hand-offs, ~12-23 us each, and a step has a dozen) -- only over ``nccl``; if the capture fails on
+    any rank, every rank falls back to the segmented recording together (one MIN all-reduce)."""
 
     def __init__(self, pp: PartitionedPropagator, weight: Tensor, alphas: Sequence[float], lr: float = 0.005,
                  decay: float = 1e-4, batch: int = 1024, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
@@ -77,6 +80,9 @@ class PartitionedTrainer:
             raise ValueError("this rank owns no user rows: a partition with more ranks than users cannot train")
         self.stats = torch.zeros(3, dtype=torch.float32, device=dev)
         self.use_graphs = bool(graphs) and dev.type == "cuda"
+        self.full_graph = graphs == "full" and self.use_graphs
+        self._full = None                          # the whole step as one graph (graphs="full"), once recorded
+        self.full_error: Optional[str] = None
         self.warmup = int(warmup)
         self._actions: Optional[list] = None       # recorded: ("graph", g) | ("start", tensor) | ("wait", slot) | ("reduce", t)
         self._recording = None
@@ -178,7 +184,57 @@ class PartitionedTrainer:
         torch.cuda.current_stream(dev).wait_stream(stream)
         self._actions, self._n_slots = rec["actions"], len(rec["handles"])
 
+    def _record_full(self) -> bool:
+        """The whole step, collectives included, as ONE graph.  Returns whether EVERY rank recorded it (else nothing is kept
+        and the caller records the segmented form).  The capture runs on a side stream and is always ended."""
+        import warnings
+        import torch.distributed as dist
+        from . import propagate
+        dev = self.w.device
+        comm = self.pp.comm
+        active = getattr(comm, "active", self.pp.world > 1)
+        ok = 1
+        # (no process group at all: a measurement harness with the collectives stubbed out -- nothing there to capture)
+        backend = dist.get_backend(self.pp.group) if dist.is_initialized() else None
+        if active and backend not in (None, "nccl"):
+            self.full_error, ok = f"backend {backend} cannot be captured", 0
+        graph = torch.cuda.CUDAGraph()
+        if ok:
+            torch.cuda.synchronize(dev)
+            current, side = torch.cuda.current_stream(dev), torch.cuda.Stream(dev)
+            side.wait_stream(current)
+            log, propagate.HOP_EVENT_LOG = propagate.HOP_EVENT_LOG, None
+            try:
+                with torch.cuda.stream(side):
+                    graph.capture_begin(capture_error_mode="thread_local")
+                    try:
+                        self._body()
+                    except Exception as exc:                  # noqa: BLE001
+                        self.full_error, ok = f"{type(exc).__name__}: {exc}", 0
+                    finally:
+                        try:
+                            with warnings.catch_warnings():
+                                warnings.filterwarnings("ignore", message="The CUDA Graph is empty")
+                                graph.capture_end()
+                        except Exception as exc:              # noqa: BLE001
+                            self.full_error, ok = self.full_error or f"{type(exc).__name__}: {exc}", 0
+            except Exception as exc:                          # noqa: BLE001
+                self.full_error, ok = self.full_error or f"{type(exc).__name__}: {exc}", 0
+            finally:
+                propagate.HOP_EVENT_LOG = log
+            current.wait_stream(side)
+        if active and backend is not None:
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pp.group)
+            ok = int(flag.item())
+        if ok:
+            self._full = graph
+        return bool(ok)
+
     def _replay(self) -> None:
+        if self._full is not None:
+            self._full.replay()
+            return
         comm = self.pp.comm
         handles = [None] * self._n_slots
         for act in self._actions:
@@ -204,16 +260,19 @@ class PartitionedTrainer:
         with torch.no_grad():
             if not self.use_graphs:
                 self._body()
-            elif self._actions is not None:
+            elif self._actions is not None or self._full is not None:
                 self._replay()
             elif self._steps_seen < self.warmup:
                 self._body()                       # eager: builds every lazy work plan and scratch buffer first
             else:
-                self._record()                     # the recording run IS this step (captured work does not execute ...
+                if not (self.full_graph and self._record_full()):
+                    self._record()                 # the recording run IS this step (captured work does not execute ...
                 self._replay()                     # ... so it is replayed once right away)
         self._steps_seen += 1
         return self.stats
 
     @property
     def graph_launches(self) -> int:
+        if self._full is not None:
+            return 1
         return 0 if self._actions is None else sum(1 for a in self._actions if a[0] == "graph")

@@ -175,7 +175,7 @@ def _train_worker(rank, world, port, q, backend="gloo"):
         from gnn_ecommerce_amd.trainer import PartitionedTrainer
         lg.propagate.SEED_ROWS_FACTOR = 0
         tables = {}
-        for graphs in (False, True):
+        for graphs in (False, True, "full"):
             wt = w0.clone()
             tr = PartitionedTrainer(pp, wt, [0.25] * 4, lr=0.005, decay=decay, batch=batch, graphs=graphs, warmup=1)
             stats = []
@@ -188,6 +188,11 @@ def _train_worker(rank, world, port, q, backend="gloo"):
         res["trainer_graph_equals_eager"] = bool(torch.equal(tables[True][0], tables[False][0])
                                                  and torch.equal(tables[True][2], tables[False][2]))
         res["trainer_graph_launches"] = tables[True][3]
+        # graphs="full": the whole step as ONE graph with the collectives inside over nccl; elsewhere every rank falls back to
+        # the segmented recording together -- the same table either way
+        res["trainer_full_equals_eager"] = bool(torch.equal(tables["full"][0], tables[False][0])
+                                                and torch.equal(tables["full"][2], tables[False][2]))
+        res["trainer_full_launches"] = tables["full"][3]
         first = tables[False][1]
         res["trainer_own"] = rel(first[lo:hi] - w0[lo:hi], ref_w[lo:hi] - w0[lo:hi])
         res["trainer_items"] = rel(first[g.n_users:] - w0[g.n_users:], ref_w[g.n_users:] - w0[g.n_users:])
@@ -204,6 +209,7 @@ def test_two_ranks_training_step_matches_single_gpu(device):
         assert r["seeded_bpr"] <= 1e-5 and r["seeded_reg"] <= 1e-5 and r["seeded_own"] <= 1e-5 and r["seeded_items"] <= 1e-5, (rank, r)
         assert r["seeded_node"] and not r["node"], (rank, r)
         assert r["trainer_graph_equals_eager"] and r["trainer_graph_launches"] >= 2, (rank, r)
+        assert r["trainer_full_equals_eager"] and r["trainer_full_launches"] >= 2, (rank, r)     # gloo: segments, agreed
         assert r["trainer_own"] <= 1e-5 and r["trainer_items"] <= 1e-5 and r["trainer_bpr"] <= 1e-5, (rank, r)
         assert r["adam_own"] <= 1e-5 and r["adam_items"] <= 1e-5 and r["adam_foreign_untouched"], (rank, r)
 
@@ -404,7 +410,7 @@ def test_the_multi_gpu_training_harness_runs_two_ranks_on_one_gpu(device):
     import json
     import subprocess
     lines = []
-    for extra in ([], ["--graphs"]):
+    for extra in ([], ["--graphs"], ["--graphs", "full"]):       # (over gloo "full" falls back to the segments, on every rank)
         proc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_dist.py"), "--gpus", "2", "--backend", "gloo",
                                "--config", "small", "--steps", "6", "--warmup", "4", "--batch", "256"] + extra,
                               capture_output=True, text=True, timeout=600)
@@ -416,6 +422,7 @@ def test_the_multi_gpu_training_harness_runs_two_ranks_on_one_gpu(device):
         assert line["n_gpus"] == 2 and line["unit"] == "steps/s" and line["value"] > 0
         assert 0.0 < line["loss"]["bpr"] < 0.6932 and line["loss"]["reg"] > 0
     assert abs(lines[0]["loss"]["total"] - lines[1]["loss"]["total"]) <= 1e-6 * lines[0]["loss"]["total"]
+    assert lines[2]["loss"]["total"] == lines[1]["loss"]["total"] and "declined" in lines[2]["config"]["trainer"]
 
 
 def test_recorded_forward_replays_and_falls_back_cleanly(device):

@@ -53,5 +53,6 @@ def test_one_rank_goes_through_the_rccl_process_group(device, monkeypatch):
     assert r["bpr"] <= 1e-5 and r["reg"] <= 1e-5 and r["own"] <= 1e-5 and r["items"] <= 1e-5, r
     assert r["seeded_bpr"] <= 1e-5 and r["seeded_own"] <= 1e-5 and r["seeded_items"] <= 1e-5 and r["seeded_node"], r
     assert r["trainer_graph_equals_eager"] and r["trainer_graph_launches"] >= 2, r
+    assert r["trainer_full_equals_eager"] and r["trainer_full_launches"] == 1, r      # ONE graph, the collectives inside
     assert r["trainer_own"] <= 1e-5 and r["trainer_items"] <= 1e-5 and r["trainer_bpr"] <= 1e-5, r
     assert r["adam_own"] <= 1e-5 and r["adam_items"] <= 1e-5, r

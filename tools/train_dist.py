@@ -31,7 +31,9 @@ def parse():
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--config", choices=["cosmetics", "small"], default="cosmetics")
-    ap.add_argument("--graphs", action="store_true", help="record the step as HIP graphs between the collectives")
+    ap.add_argument("--graphs", nargs="?", const="segments", default=None, choices=["segments", "full"],
+                    help="record the step as HIP graphs: segments = one graph per stretch of work between two collectives; "
+                         "full = the whole step as ONE graph with the collectives inside (nccl only; falls back to segments)")
     ap.add_argument("--backend", default="nccl")
     return ap.parse_args()
 
@@ -74,7 +76,7 @@ def main():
     pp = PartitionedPropagator(ei, ew, g.n_users, g.n_items, rank, world)
     w = synth.xavier_table(g.num_nodes, args.dim, 0, dev)
     alphas = [1.0 / (args.layers + 1)] * (args.layers + 1)
-    tr = PartitionedTrainer(pp, w, alphas, lr=0.005, decay=1e-4, batch=args.batch, graphs=args.graphs)
+    tr = PartitionedTrainer(pp, w, alphas, lr=0.005, decay=1e-4, batch=args.batch, graphs={None: False, "segments": True, "full": "full"}[args.graphs])
     gen = torch.Generator().manual_seed(0)             # the same stream of batches on every rank
 
     def step():
@@ -111,7 +113,9 @@ def main():
                        "parallelism": f"user-range x{world}, items replicated, [n_items, D] all-reduce per hop (the forward's last "
                                       f"layer: [2B, D]) over {args.backend}" + ("" if args.backend == "nccl" or world == 1
                                                                               else " (rehearsal, not RCCL)"),
-                       "trainer": "PartitionedTrainer, " + ("recorded as HIP graphs between the collectives" if args.graphs else "eager"),
+                       "trainer": "PartitionedTrainer, " + ({"segments": "recorded as HIP graphs between the collectives", "full": "recorded as "
+                                   f"{tr.graph_launches} HIP graph(s), collectives inside" + (f" (one graph declined: {tr.full_error})" if tr.full_error else "")}
+                                  .get(args.graphs, "eager")),
                        "own_users": [pp.u0, pp.u1]},
             "loss": {"bpr": bpr, "reg": reg, "total": loss}}), flush=True)
     if world > 1:

@@ -28,7 +28,7 @@ ap.add_argument("--world", type=int, default=1, help="> 1: the rank-local step o
                 "rank owns) -- local work only, what the exchange adds can only be measured on a multi-GPU node")
 ap.add_argument("--rank", type=int, default=0)
 ap.add_argument("--dense-partition", action="store_true", help="with --world: the dense partitioned backward (round 3)")
-ap.add_argument("--trainer", choices=["autograd", "eager", "graphs"], default="autograd",
+ap.add_argument("--trainer", choices=["autograd", "eager", "graphs", "full"], default="autograd",
                 help="with --world: autograd = partitioned_bpr_loss + backward() + optim.Adam(row_ranges); eager / graphs = "
                      "trainer.PartitionedTrainer (the same launches without autograd / recorded once as HIP graphs between "
                      "the collectives and replayed)")
@@ -50,7 +50,7 @@ if args.world > 1 or args.trainer != "autograd":     # --world 1 --trainer graph
     pgen = torch.Generator().manual_seed(0)
     if args.trainer != "autograd":
         from gnn_ecommerce_amd.trainer import PartitionedTrainer
-        tr = PartitionedTrainer(pp, w.detach(), alphas, lr=0.005, decay=1e-4, batch=args.batch, graphs=args.trainer == "graphs")
+        tr = PartitionedTrainer(pp, w.detach(), alphas, lr=0.005, decay=1e-4, batch=args.batch, graphs={"graphs": True, "full": "full"}.get(args.trainer, False))
     def pstep():
         if args.trainer != "autograd":
             u = torch.randint(0, g.n_users, (args.batch,), generator=pgen).to(dev)
