@@ -262,6 +262,85 @@ def rank_local_bench(graph, ei, ew, dim, layers, world, ranks, single_hop_s):
         dist.all_reduce = real_all_reduce
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def c_stdout_to_stderr():
+    """RCCL prints a version banner with printf when a communicator is created; this process's stdout carries ONE JSON line.
+    While the block runs, file descriptor 1 points at stderr; the C library's buffer is flushed before it is restored."""
+    import ctypes
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:                                     # noqa: BLE001
+            pass
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
+def exchange_machinery_bench(graph, ei, ew, dim, layers, world, rank):
+    """What torch's collectives cost a rank's hop BEFORE any byte moves, measured on this one GPU: RCCL refuses two ranks on
+    one device, but a ONE-rank nccl group is legal and its all-reduce is an identity -- so rank ``rank`` of a ``world``-way
+    partition runs its forward with every per-hop all-reduce issued to such a group (event on the launch stream, RCCL's
+    stream waits, the collective, event, the launch stream waits), eagerly and as partition.RecordedForward replays it (one
+    HIP graph, the collectives inside).  Never fatal: any failure comes back as {"error": ...}."""
+    import datetime
+    import socket
+    import torch.distributed as dist
+    from gnn_ecommerce_amd import partition, synth
+    made_group = False
+    try:
+        dev = ei.device
+        if not dist.is_initialized():
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                port = s.getsockname()[1]
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev,
+                                    timeout=datetime.timedelta(seconds=60))
+            made_group = True
+        alphas = tuple([1.0 / (layers + 1)] * (layers + 1))
+        x0 = synth.xavier_table(graph.num_nodes, dim, SEED, dev)
+        pp = partition.PartitionedPropagator(ei, ew, graph.n_users, graph.n_items, rank, world)
+        pp.comm = partition.Comm(world, None)             # active: its all-reduces go to the default (one-rank) group
+        rec = partition.RecordedForward(pp, x0, alphas)
+        out = {}
+        for name, fn in (("eager", lambda: pp.propagate_sum(x0, alphas)), ("recorded", rec)):
+            times = []
+            for rnd in range(4):
+                torch.cuda.synchronize()
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                for _ in range(10):
+                    fn()
+                e.record()
+                torch.cuda.synchronize()
+                if rnd:
+                    times.append(s.elapsed_time(e) / (10 * layers) * 1e3)
+            out[name] = statistics.median(times)
+        return {"world": world, "rank": rank, "us_per_hop_eager_collectives": out["eager"],
+                "us_per_hop_recorded_with_collectives": out["recorded"], "recorded": rec.recorded, "capture_error": rec.error,
+                "what": "the same rank's forward with its per-hop all-reduce issued to a REAL one-rank nccl process group "
+                        "(an identity: the collective's machinery alone, no byte moves) -- eagerly, and captured once with "
+                        "its collectives into one HIP graph and replayed (partition.RecordedForward, what bench.py --gpus N "
+                        "times); medians of three batches of ten back-to-back forwards; compare rank_local.us_per_hop "
+                        "(collectives stubbed out)"}
+    except Exception as exc:                                  # noqa: BLE001 -- a rider: never fatal for the bench line
+        return {"error": f"{type(exc).__name__}: {exc}"[:300]}
+    finally:
+        if made_group:
+            try:
+                dist.destroy_process_group()
+            except Exception:                                 # noqa: BLE001
+                pass
+
+
 def workload_name(args, world: int) -> str:
     """Which BASELINE.json configuration the arguments describe."""
     if args.config != "cosmetics":
@@ -310,10 +389,11 @@ def main():
     dev = torch.device(f"cuda:{local_rank % max(torch.cuda.device_count(), 1)}")
     torch.cuda.set_device(dev)
     if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(args.backend)
+        with c_stdout_to_stderr():                         # the communicator's banner does not belong on stdout
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(args.backend)
 
     import gnn_ecommerce_amd as lg
     from gnn_ecommerce_amd import propagate, synth
@@ -435,6 +515,8 @@ def main():
             train_lines.append(entry)
     if default_run and not args.no_rank_local:
         rank_local = rank_local_bench(graph, keep_coo[0], keep_coo[1], args.dim, args.layers, 8, (0, 5), main_m["hop_mean_s"])
+        with c_stdout_to_stderr():
+            rank_local["exchange_machinery"] = exchange_machinery_bench(graph, keep_coo[0], keep_coo[1], args.dim, args.layers, 8, 5)
     del keep_coo
     if rank == 0:
         elapsed = main_m["elapsed"]
