@@ -63,10 +63,19 @@ def main():
     dev = torch.device(f"cuda:{local_rank % max(torch.cuda.device_count(), 1)}")
     torch.cuda.set_device(dev)
     if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(args.backend)
+        # (the communicator's printf banner goes to stderr: stdout carries the one JSON line)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(args.backend)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     from gnn_ecommerce_amd import synth
     from gnn_ecommerce_amd.partition import PartitionedPropagator
     from gnn_ecommerce_amd.trainer import PartitionedTrainer
