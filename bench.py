@@ -57,6 +57,10 @@ def parse():
     ap.add_argument("--no-rank-local", action="store_true", help="skip the rank-local measurement (one rank of an 8-way "
                     "partition on this GPU, collectives stubbed)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = auto)")
+    ap.add_argument("--rehearse-partition", action="store_true", help="ONE GPU: run the N > 1 code path (process group with "
+                    "device_id, PartitionedPropagator, RecordedForward, barrier fences, MAX over ranks) as a partition of one rank "
+                    "whose collectives go to a real one-rank nccl group (LGCN_COMM_FORCE) -- a rehearsal of the multi-GPU launch, "
+                    "not a measurement of the fabric")
     ap.add_argument("--no-graph", action="store_true", help="N > 1: the eager forward instead of the forward recorded as one HIP "
                     "graph with its collectives (partition.RecordedForward)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
@@ -388,7 +392,17 @@ def main():
         args.gpus = world
     dev = torch.device(f"cuda:{local_rank % max(torch.cuda.device_count(), 1)}")
     torch.cuda.set_device(dev)
-    if world > 1:
+    partitioned = world > 1 or args.rehearse_partition      # the multi-rank code path (with ONE rank when rehearsed)
+    if args.rehearse_partition and world == 1:
+        import socket
+        os.environ["LGCN_COMM_FORCE"] = "1"                 # read when gnn_ecommerce_amd.partition is imported (below)
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sock.getsockname()[1]))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if partitioned:
         with c_stdout_to_stderr():                         # the communicator's banner does not belong on stdout
             if args.backend == "nccl":
                 dist.init_process_group("nccl", device_id=dev)
@@ -407,7 +421,7 @@ def main():
 
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    if world == 1:
+    if not partitioned:
         pg = lg.PropGraph(ei, ew, n)
         torch.cuda.synchronize()
         t_build = time.perf_counter() - t0
@@ -435,12 +449,14 @@ def main():
                 recorded_steps.append(rec)
                 return rec
         parallelism = (f"user-range x{world}, items replicated, all-reduce [n_items,D]/hop over {args.backend}"
-                       + ("" if args.backend == "nccl" else " (rehearsal, not RCCL)"))
+                       + ("" if args.backend == "nccl" else " (rehearsal, not RCCL)")
+                       + (" -- ONE rank going through the real process group: a rehearsal of the multi-GPU launch, the "
+                          "collectives are identities" if args.rehearse_partition and world == 1 else ""))
     keep_coo = (ei, ew)
     del ei, ew
 
     def fence():
-        if world > 1:
+        if partitioned:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -459,7 +475,7 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
         hop_events, propagate.HOP_EVENT_LOG = propagate.HOP_EVENT_LOG, None
-        if world > 1:
+        if partitioned:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = tmax.item()
@@ -475,7 +491,7 @@ def main():
         """HBM-side bytes per hop from separate rocprofv3 PMC passes (profiles/collect.sh): quoted only while the kernel
         source they were measured on is the one running now, otherwise null.  Not measured by THIS process."""
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if world == 1 and os.path.isfile(tpath):
+        if not partitioned and os.path.isfile(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
             if tj.get("kernel_source_sha256") == kernel_source_hash():
@@ -494,13 +510,13 @@ def main():
     # configs[2] (same graph, 5 layers, emb_dim 90) rides along on the default single-GPU run: it is the configuration
     # furthest below its roofline, so the driver's own clock sees it too
     deep_m = None
-    if world == 1 and args.config == "cosmetics" and (args.layers, args.dim) == (LAYERS, DIM) and not args.no_deep:
+    if not partitioned and args.config == "cosmetics" and (args.layers, args.dim) == (LAYERS, DIM) and not args.no_deep:
         t0 = time.perf_counter()
         pg.prepare(90)
         deep_plan = time.perf_counter() - t0
         deep_steps = max(5, args.steps // 2)
         deep_m = measure(90, 5, deep_steps, args.warmup)
-    default_run = world == 1 and args.config == "cosmetics" and (args.layers, args.dim) == (LAYERS, DIM)
+    default_run = not partitioned and args.config == "cosmetics" and (args.layers, args.dim) == (LAYERS, DIM)
     train_lines, rank_local = [], None
     if default_run and not args.no_train:
         for t_dim, t_layers, t_steps, with_cpu in ((64, 3, max(20, args.steps), True), (90, 5, max(10, args.steps // 2), False)):
@@ -534,7 +550,7 @@ def main():
             "config": {"workload": f"{workload_name(args, world)}: {graph.n_users} users x {graph.n_items} items, "
                                    f"{nnz} directed edges, {args.layers} LGConv layers, emb_dim {args.dim}, "
                                    "get_embedding (K hops + fused layer sum)",
-                       "parallelism": parallelism + ("" if world == 1 else (
+                       "parallelism": parallelism + ("" if not partitioned else (
                            ", forward recorded as one HIP graph (collectives included)" if recorded_steps and recorded_steps[0].recorded
                            else ", eager forward" + (f" (capture declined: {recorded_steps[0].error})" if recorded_steps and recorded_steps[0].error else ""))),
                        "seed": SEED,
@@ -557,10 +573,10 @@ def main():
             line.setdefault("other_configs", []).extend(train_lines)
         if rank_local is not None:
             line["rank_local"] = rank_local
-        if world == 1 and not args.no_cpu_baseline:
+        if not partitioned and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(graph, args.layers, args.dim, args.cpu_threads)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if partitioned:
         dist.destroy_process_group()
 
 

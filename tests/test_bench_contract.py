@@ -65,3 +65,18 @@ def test_plain_python_launch_with_gpus_2_starts_its_own_ranks(device):
     assert out.returncode == 0, out.stderr[-2000:]
     d = check_line(out.stdout, 2, 2, 1)
     assert "cpu_baseline" not in d
+
+
+def test_the_multi_gpu_code_path_rehearsed_with_one_rank_over_rccl(device):
+    """`bench.py --rehearse-partition`: the N > 1 code path -- nccl process group with device_id, PartitionedPropagator, the
+    forward recorded with its collectives as one HIP graph, barrier fences, MAX over ranks -- as a partition of ONE rank over
+    the real backend (RCCL refuses two ranks on one device); stdout still carries exactly one line (the communicator's
+    banner goes to stderr)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rehearse-partition", "--steps", "3", "--warmup", "1",
+                          "--config", "small"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert len(out.stdout.strip().splitlines()) == 1, out.stdout
+    d = check_line(out.stdout, 1, 3, 1)
+    assert "recorded as one HIP graph (collectives included)" in d["config"]["parallelism"], d["config"]["parallelism"]
+    assert "cpu_baseline" not in d and d["roofline"]["launches_timed"] == 3 * 3
