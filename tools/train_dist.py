@@ -35,6 +35,8 @@ def parse():
                     help="record the step as HIP graphs: segments = one graph per stretch of work between two collectives; "
                          "full = the whole step as ONE graph with the collectives inside (nccl only; falls back to segments)")
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--rehearse", action="store_true", help="ONE GPU: the same code path as a partition of ONE rank whose "
+                    "collectives go to a real one-rank process group (LGCN_COMM_FORCE) -- a rehearsal of the launch, not of the fabric")
     return ap.parse_args()
 
 
@@ -60,9 +62,19 @@ def main():
     import torch
     import torch.distributed as dist
     rank, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    grouped = world > 1 or args.rehearse
+    if args.rehearse and world == 1:
+        import socket
+        os.environ["LGCN_COMM_FORCE"] = "1"                 # read when gnn_ecommerce_amd.partition is imported (below)
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sock.getsockname()[1]))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     dev = torch.device(f"cuda:{local_rank % max(torch.cuda.device_count(), 1)}")
     torch.cuda.set_device(dev)
-    if world > 1:
+    if grouped:
         # (the communicator's printf banner goes to stderr: stdout carries the one JSON line)
         sys.stdout.flush()
         saved = os.dup(1)
@@ -95,7 +107,7 @@ def main():
         return tr.step(u, p, n)
 
     def fence():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -107,7 +119,7 @@ def main():
         stats = step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
@@ -127,7 +139,7 @@ def main():
                                   .get(args.graphs, "eager")),
                        "own_users": [pp.u0, pp.u1]},
             "loss": {"bpr": bpr, "reg": reg, "total": loss}}), flush=True)
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 
