@@ -216,7 +216,7 @@ def regularization_loss(init_embed: Tensor, batch_size: int, batch_usr: Tensor, 
     dense two-node path, the graph already consumed) this is upstream's expression on plain torch ops."""
     hook = getattr(init_embed, "_lgcn_reg_hook", None)
     if (hook is not None and not hook.spent and hook.token is not None and hook.weight is init_embed
-            and torch.is_grad_enabled() and init_embed.is_cuda
+            and torch.is_grad_enabled() and init_embed.is_cuda and batch_size > 0       # (size 0: upstream's inf / nan)
             and all(routable_index(t) for t in (batch_usr, batch_pos, batch_neg))):
         return regularization_through(hook, batch_size, batch_usr, batch_pos, batch_neg, decay)
     reg_loss = (1 / 2) * (init_embed[batch_usr].norm().pow(2) + init_embed[batch_pos].norm().pow(2)
